@@ -1,0 +1,175 @@
+/*
+ * spectro.h -- C ABI of libspectro.so, the MI355X (gfx950) STFT/PSD engine.
+ *
+ * This is the drop-in boundary for ONE hot path of the reference application:
+ * the call
+ *
+ *     f, t, Sxx = spectrogram(data, fs=fs, nperseg=nperseg,
+ *                             scaling="density", mode="psd")
+ *
+ * made at /root/reference PlotEngine.py:113 and PlotEngine.py:232
+ * (`spectrogram` = scipy.signal.spectrogram, PlotEngine.py:8), plus the numpy
+ * post-processing that consumes its result (PlotEngine.py:114-131, 238-241,
+ * 686-719).  The reference is pure Python, so a maintainer binds this library
+ * with ctypes; nothing here mentions torch or numpy.
+ *
+ * Conventions
+ *   - every entry point returns 0 on success or a negative sg_status;
+ *     sg_last_error() returns a thread-local message for the last failure.
+ *   - the caller owns every buffer; a plan owns only its device tables
+ *     (window, twiddles).  Pointers named *_dev are device pointers of the
+ *     current HIP device, `stream` is a hipStream_t passed as void* (NULL =
+ *     the default stream).  No entry point synchronises unless it says so.
+ *   - spectra are FRAME-MAJOR on the device: out[clip][frame][bin]; the Python
+ *     shim returns the transposed view [bin][frame] exactly like
+ *     scipy/signal/_spectral_py.py:2153 (moveaxis of a frame-major result).
+ *   - re-entrant per (plan, stream); no global mutable state besides the
+ *     thread-local error string.
+ */
+#ifndef SPECTRO_H
+#define SPECTRO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SG_VERSION 100 /* 0.1.0 */
+
+typedef enum sg_status {
+    SG_OK = 0,
+    SG_ERR_ARG = -1,         /* bad argument (shim raises ValueError)            */
+    SG_ERR_HIP = -2,         /* HIP runtime failure (shim raises RuntimeError)   */
+    SG_ERR_UNSUPPORTED = -3, /* valid request the device path does not cover     */
+    SG_ERR_NO_DEVICE = -4
+} sg_status;
+
+/* scipy's `detrend=` (scipy/signal/_spectral_py.py:2070-2072) */
+typedef enum sg_detrend { SG_DETREND_NONE = 0, SG_DETREND_CONSTANT = 1, SG_DETREND_LINEAR = 2 } sg_detrend;
+/* scipy's `scaling=` (scipy:2086-2089) */
+typedef enum sg_scaling { SG_SCALING_DENSITY = 0, SG_SCALING_SPECTRUM = 1 } sg_scaling;
+/* scipy's `mode=` (scipy:960-985). PSD/MAGNITUDE/ANGLE write one real per bin,
+ * COMPLEX writes interleaved (re, im). 'phase' = unwrap(ANGLE) is done by the caller. */
+typedef enum sg_mode { SG_MODE_PSD = 0, SG_MODE_MAGNITUDE = 1, SG_MODE_COMPLEX = 2, SG_MODE_ANGLE = 3 } sg_mode;
+/* arithmetic type of the path = input precision (scipy:1976-1981: f32 in -> f32 out) */
+typedef enum sg_dtype { SG_F32 = 0, SG_F64 = 1 } sg_dtype;
+
+typedef struct sg_plan sg_plan;
+
+/* ---- library / device ------------------------------------------------- */
+int sg_version(void);
+const char* sg_last_error(void);
+int sg_device_count(int* count);
+/* Select `device` for the calling thread (hipSetDevice) and check it is gfx950. */
+int sg_init(int device);
+/* name (e.g. "gfx950"), CU count and HBM bytes of the current device */
+int sg_device_info(char* arch, size_t arch_len, int* compute_units, uint64_t* hbm_bytes);
+
+/* ---- raw device memory / streams (so a ctypes host needs nothing else) -- */
+int sg_malloc(void** dev_ptr, size_t bytes);
+int sg_free(void* dev_ptr);
+int sg_host_alloc(void** host_ptr, size_t bytes); /* pinned */
+int sg_host_free(void* host_ptr);
+int sg_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream);
+int sg_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);
+int sg_memset(void* dst_dev, int value, size_t bytes, void* stream);
+int sg_stream_create(void** stream);
+int sg_stream_destroy(void* stream);
+int sg_stream_sync(void* stream); /* blocks the caller */
+
+/* ---- plan ------------------------------------------------------------- */
+/*
+ * Replaces the argument triage of scipy.signal.spectrogram /_spectral_helper
+ * (scipy:967-970, 2031-2041, 2083-2091) for one (nperseg, nfft, hop, window).
+ *   nperseg  samples per frame (>= 1); nfft >= nperseg (zero padded); 1 <= hop <= nperseg
+ *            (hop = nperseg - noverlap; the reference's default is nperseg - nperseg/8)
+ *   window   nperseg doubles on the HOST (the shim builds scipy's periodic Tukey(0.25)
+ *            for the reference call); cast to `dtype` like scipy:2083-2084
+ *   fs       sampling rate; scale = 1/(fs*sum(w^2)) or 1/sum(w)^2 (scipy:2086-2089),
+ *            computed in `dtype` precision like scipy does
+ * Supported on the device: every nfft >= 2 (powers of two by the Stockham kernels,
+ * everything else by Bluestein on top of them); SG_F64 up to nfft = 8192 (pow2) .
+ */
+int sg_plan_create(sg_plan** plan, int nperseg, int nfft, int hop, const double* window,
+                   int detrend, double fs, int scaling, int mode, int dtype);
+int sg_plan_destroy(sg_plan* plan);
+/* A2: (n_samples - nperseg)/hop + 1, 0 when n_samples < nperseg (scipy:2180-2188) */
+int sg_plan_n_frames(const sg_plan* plan, int64_t n_samples, int64_t* n_frames);
+/* nfft/2 + 1 */
+int sg_plan_n_bins(const sg_plan* plan, int* n_bins);
+/* the scale factor the kernels multiply |X|^2 with (as double) */
+int sg_plan_scale(const sg_plan* plan, double* scale);
+/* name of the kernel family the plan dispatches to: "r8x3", "stockham", "bluestein" */
+const char* sg_plan_kernel(const sg_plan* plan);
+/* Tests / benchmarks: route the plan to another family that can run it ("stockham" for an
+ * r8x3 plan).  SG_ERR_UNSUPPORTED if that family cannot run this plan. */
+int sg_plan_force_kernel(sg_plan* plan, const char* name);
+/* A7 on the host, bit-exact with scipy:2115 and scipy:2136-2137 */
+int sg_freqs(int nfft, double fs, double* f_out /* nfft/2+1 */);
+int sg_times(int64_t n_samples, int nperseg, int hop, double fs, double* t_out /* n_frames */);
+
+/* ---- the hot path (A2..A6) -------------------------------------------- */
+/*
+ * Framing + detrend + window + real FFT + |X|^2*scale with one-sided doubling for
+ * n_clips signals of n_samples each (clip c starts at x_dev + c*clip_stride elements).
+ * out_dev receives [n_clips][n_frames][n_bins] (x2 for SG_MODE_COMPLEX) elements of
+ * the plan's dtype; clip c starts at out_dev + c*out_clip_stride elements
+ * (out_clip_stride >= n_frames*n_bins*(complex?2:1)).  Asynchronous on `stream`.
+ */
+int sg_stft(const sg_plan* plan, const void* x_dev, int64_t n_samples, int64_t clip_stride,
+            int n_clips, void* out_dev, int64_t out_clip_stride, void* stream);
+/* int16 PCM input converted on the fly (WAV path); plan dtype must be SG_F32.
+ * Samples are used as-is (no 1/32768 scaling), i.e. like numpy's int16 -> float cast. */
+int sg_stft_i16(const sg_plan* plan, const int16_t* x_dev, int64_t n_samples, int64_t clip_stride,
+                int n_clips, float* out_dev, int64_t out_clip_stride, void* stream);
+/*
+ * Same framing/FFT but the spectrum never reaches HBM: per frame only
+ * p[frame] = sum_{k in [k_lo, k_hi]} Sxx[k, frame] is written (A11 band sum,
+ * PlotEngine.py:238-239).  band_out_dev: [n_clips][n_frames] of the plan's dtype.
+ */
+int sg_stft_band_power(const sg_plan* plan, const void* x_dev, int64_t n_samples,
+                       int64_t clip_stride, int n_clips, int k_lo, int k_hi,
+                       void* band_out_dev, int64_t out_clip_stride, void* stream);
+
+/* ---- epilogues over a frame-major spectrum (A8..A13) ------------------ */
+/* `dtype` (sg_dtype) is the element type of every spectrum / image / band buffer below. */
+/* mm_dev[0] = min, mm_dev[1] = max over rows [0,n_frames) x bins [k_lo,k_hi] of spec (row stride n_bins).
+ * mm_dev: 2 elements of dtype (used as scratch while the kernel runs). */
+int sg_minmax(const void* spec_dev, int dtype, int64_t n_frames, int n_bins, int k_lo, int k_hi,
+              void* mm_dev, void* stream);
+/*
+ * A9/A10 (PlotEngine.py:126-131): img = clip(S/(base+1e-20),0,1); if log_scale:
+ * db = 10*log10(img+1e-12), img = (db-db_min)/(db_max-db_min) or 0 when range <= 1e-6.
+ * base = global_max if > 0 else max(S) over the band; db_min/db_max follow from the
+ * band's min/max because the map is monotone.  Writes img_dev[n_frames][k_hi-k_lo+1].
+ * mm_dev: scratch of 2 elements.  Asynchronous.
+ */
+int sg_normalise_image(const void* spec_dev, int dtype, int64_t n_frames, int n_bins, int k_lo, int k_hi,
+                       int log_scale, double global_max, void* img_dev, void* mm_dev, void* stream);
+/* A11 (PlotEngine.py:239-241): feat[f] = (log10(p[f]+1e-20), diff with prepend) from band sums p. */
+int sg_band_features(const void* band_dev, int dtype, int64_t n_frames, void* feat_dev /* [n_frames][2] */,
+                     void* stream);
+/* A11 without the fused kernel: p[f] = sum_{k_lo..k_hi} spec[f][k] */
+int sg_band_sum(const void* spec_dev, int dtype, int64_t n_frames, int n_bins, int k_lo, int k_hi,
+                void* band_dev, void* stream);
+/* A12/A13 (PlotEngine.py:686-719): sums_dev[b] = sum over frames of sum_{k in [lo_b, hi_b)} max(0, spec[f][k])
+ * for n_bands (<= 16) half-open bin ranges given on the host; accumulates in double. */
+int sg_band_totals(const void* spec_dev, int dtype, int64_t n_frames, int n_bins, int n_bands,
+                   const int* k_lo_host, const int* k_hi_host, double* sums_dev, void* stream);
+/* Copy bins [k_lo,k_hi] of every frame into dst_dev[n_frames][k_hi-k_lo+1] (A8 mask + store). */
+int sg_slice_bins(const void* spec_dev, int dtype, int64_t n_frames, int n_bins, int k_lo, int k_hi,
+                  void* dst_dev, void* stream);
+
+/* ---- timing helper used by bench.py (HIP events on `stream`) ---------- */
+/* Runs sg_stft `iters` times back to back between two hipEvents and returns the
+ * average milliseconds per launch.  Synchronises `stream`. */
+int sg_time_stft(const sg_plan* plan, const void* x_dev, int64_t n_samples, int64_t clip_stride,
+                 int n_clips, void* out_dev, int64_t out_clip_stride, void* stream, int iters,
+                 float* ms_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPECTRO_H */

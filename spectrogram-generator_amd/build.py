@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Build libspectro.so (HIP, gfx950 only) in-tree.
+
+    python spectrogram-generator_amd/build.py [--force] [--verbose]
+
+hipcc cross-compiles without a GPU.  The .so lands in spectrogram-generator_amd/lib/
+(git-ignored, but it travels to the GPU box with the repo snapshot).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libspectro.so")
+SOURCES = ["spectro_api.hip", "stft_r8x3.hip", "stft_stockham.hip", "stft_bluestein.hip", "epilogue.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-fno-gpu-rdc",
+         "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _deps():
+    out = [os.path.join(CSRC, s) for s in SOURCES]
+    out += [os.path.join(CSRC, "spectro_internal.h"), os.path.join(ROOT, "include", "spectro.h"), __file__]
+    return out
+
+
+def up_to_date():
+    if not os.path.exists(LIB):
+        return False
+    t = os.path.getmtime(LIB)
+    return all(os.path.getmtime(d) <= t for d in _deps())
+
+
+def build(force=False, verbose=False):
+    if not force and up_to_date():
+        return LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    objs = []
+    t0 = time.time()
+    procs = []
+    for s in SOURCES:
+        obj = os.path.join(LIBDIR, s.replace(".hip", ".o"))
+        cmd = [hipcc(), *FLAGS, "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", os.path.join(CSRC, s), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        objs.append(obj)
+    failed = False
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0 or (verbose and out.strip()):
+            print(f"--- {s} ---\n{out}", flush=True)
+        failed |= p.returncode != 0
+    if failed:
+        raise RuntimeError("hipcc failed")
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        print(r.stdout)
+        raise RuntimeError("link failed")
+    if verbose:
+        print(f"built {LIB} in {time.time() - t0:.1f}s")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)

@@ -1,0 +1,362 @@
+// spectro_api.hip -- the C ABI of libspectro.so (see include/spectro.h): plans, dispatch, memory helpers.
+#include "spectro_internal.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+namespace sg {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char* what) {
+    set_error("HIP error %d (%s) in %s", static_cast<int>(e), hipGetErrorString(e), what);
+    return SG_ERR_HIP;
+}
+
+static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+static size_t esize(int dtype) { return dtype == SG_F64 ? 8 : 4; }
+
+static bool r8x3_ok(const sg_plan& p) {
+    return p.dtype == SG_F32 && p.nperseg == 1024 && p.nfft == 1024 &&
+           (p.detrend == SG_DETREND_NONE || p.detrend == SG_DETREND_CONSTANT) &&
+           (p.mode == SG_MODE_PSD || p.mode == SG_MODE_MAGNITUDE);
+}
+
+static bool stockham_ok(const sg_plan& p) {
+    if (!is_pow2(p.nfft) || p.nfft < 2) return false;
+    // LDS need of the largest case: one frame per workgroup, two nfft-real buffers + reduction scratch
+    const int M = p.nfft / 2;
+    int tpf = M / 2 < 1 ? 1 : (M / 2 > 256 ? 256 : M / 2);
+    const size_t lds = static_cast<size_t>(256 / tpf) * (2 * static_cast<size_t>(p.nfft) * esize(p.dtype) + 2 * tpf * 8);
+    return lds <= 160 * 1024;
+}
+
+template <typename T>
+static int upload(void** dev, const std::vector<T>& host) {
+    SG_HIP(hipMalloc(dev, host.size() * sizeof(T)));
+    SG_HIP(hipMemcpy(*dev, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    return SG_OK;
+}
+
+template <typename T>
+static int build_common_tables(sg_plan& p, const std::vector<double>& window) {
+    std::vector<T> w(window.size());
+    for (size_t i = 0; i < window.size(); ++i) w[i] = static_cast<T>(window[i]);
+    // scipy:2083-2089: window cast to the data precision, scale computed in that precision
+    double acc = 0.0;
+    if (p.scaling == SG_SCALING_DENSITY) {
+        for (T v : w) acc += static_cast<double>(v) * static_cast<double>(v);
+        const T sum = static_cast<T>(acc);
+        const T prod = static_cast<T>(p.fs) * sum;
+        p.scale = static_cast<double>(static_cast<T>(T(1) / prod));
+    } else {
+        for (T v : w) acc += static_cast<double>(v);
+        const T sum = static_cast<T>(acc);
+        p.scale = static_cast<double>(static_cast<T>(T(1) / (sum * sum)));
+    }
+    if (int rc = upload<T>(&p.win_dev, w)) return rc;
+    if (is_pow2(p.nfft) && p.nfft >= 2) {
+        const int half = p.nfft / 2;
+        std::vector<T> tw(2 * static_cast<size_t>(half));
+        const long double two_pi = 6.283185307179586476925286766559005768L;
+        for (int k = 0; k < half; ++k) {
+            const long double a = -two_pi * static_cast<long double>(k) / static_cast<long double>(p.nfft);
+            tw[2 * k] = static_cast<T>(cosl(a));
+            tw[2 * k + 1] = static_cast<T>(sinl(a));
+        }
+        if (int rc = upload<T>(&p.tw_dev, tw)) return rc;
+    }
+    return SG_OK;
+}
+
+static void free_tables(sg_plan* p) {
+    void** ptrs[] = {&p->win_dev, &p->tw_dev, &p->r8_tw_dev, &p->bs_chirp_dev, &p->bs_filter_dev, &p->bs_tw_dev};
+    for (void** q : ptrs) {
+        if (*q) (void)hipFree(*q);
+        *q = nullptr;
+    }
+}
+
+static int run_stft(const sg_plan* plan, StftArgs& a) {
+    if (!plan) { set_error("null plan"); return SG_ERR_ARG; }
+    if (a.n_clips < 0 || a.n_samples < 0) { set_error("negative sizes"); return SG_ERR_ARG; }
+    a.n_frames = a.n_samples < plan->nperseg ? 0 : (a.n_samples - plan->nperseg) / plan->hop + 1;
+    if (a.n_frames == 0 || a.n_clips == 0) return SG_OK;
+    if (!a.x || !a.out) { set_error("null device pointer"); return SG_ERR_ARG; }
+    if (a.n_clips > 1 && a.clip_stride < a.n_samples) { set_error("clip_stride < n_samples"); return SG_ERR_ARG; }
+    const int nbins = plan->nfft / 2 + 1;
+    const int64_t need = a.band_mode ? a.n_frames : a.n_frames * nbins * (plan->mode == SG_MODE_COMPLEX ? 2 : 1);
+    if (a.n_clips > 1 && a.out_clip_stride < need) { set_error("out_clip_stride %lld < %lld", (long long)a.out_clip_stride, (long long)need); return SG_ERR_ARG; }
+    if (a.band_mode) {
+        if (plan->mode != SG_MODE_PSD) { set_error("band power needs a psd plan"); return SG_ERR_ARG; }
+        if (a.k_lo < 0 || a.k_hi >= nbins || a.k_lo > a.k_hi) { set_error("bad band [%d,%d] of %d bins", a.k_lo, a.k_hi, nbins); return SG_ERR_ARG; }
+    }
+    switch (plan->kernel) {
+        case Kernel::R8X3: return launch_r8x3(*plan, a);
+        case Kernel::STOCKHAM: return launch_stockham(*plan, a);
+        case Kernel::BLUESTEIN: return launch_bluestein(*plan, a);
+    }
+    return SG_ERR_UNSUPPORTED;
+}
+
+}  // namespace sg
+
+using namespace sg;
+
+extern "C" {
+
+int sg_version(void) { return SG_VERSION; }
+
+const char* sg_last_error(void) { return g_err; }
+
+int sg_device_count(int* count) {
+    if (!count) { set_error("null pointer"); return SG_ERR_ARG; }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return hip_fail(e, "hipGetDeviceCount"); }
+    *count = n;
+    return SG_OK;
+}
+
+int sg_init(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_error("no HIP device visible"); return SG_ERR_NO_DEVICE; }
+    if (device < 0 || device >= n) { set_error("device %d out of range (%d visible)", device, n); return SG_ERR_ARG; }
+    SG_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    SG_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; libspectro.so carries gfx950 code only", device, prop.gcnArchName);
+        return SG_ERR_NO_DEVICE;
+    }
+    return SG_OK;
+}
+
+int sg_device_info(char* arch, size_t arch_len, int* compute_units, uint64_t* hbm_bytes) {
+    int dev = 0;
+    SG_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    SG_HIP(hipGetDeviceProperties(&prop, dev));
+    if (arch && arch_len) { strncpy(arch, prop.gcnArchName, arch_len - 1); arch[arch_len - 1] = 0; }
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+    return SG_OK;
+}
+
+int sg_malloc(void** dev_ptr, size_t bytes) {
+    if (!dev_ptr) { set_error("null pointer"); return SG_ERR_ARG; }
+    SG_HIP(hipMalloc(dev_ptr, bytes ? bytes : 1));
+    return SG_OK;
+}
+int sg_free(void* dev_ptr) { if (dev_ptr) SG_HIP(hipFree(dev_ptr)); return SG_OK; }
+int sg_host_alloc(void** host_ptr, size_t bytes) {
+    if (!host_ptr) { set_error("null pointer"); return SG_ERR_ARG; }
+    SG_HIP(hipHostMalloc(host_ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return SG_OK;
+}
+int sg_host_free(void* host_ptr) { if (host_ptr) SG_HIP(hipHostFree(host_ptr)); return SG_OK; }
+int sg_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream) {
+    if (bytes) SG_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
+    return SG_OK;
+}
+int sg_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream) {
+    if (bytes) SG_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+    return SG_OK;
+}
+int sg_memset(void* dst_dev, int value, size_t bytes, void* stream) {
+    if (bytes) SG_HIP(hipMemsetAsync(dst_dev, value, bytes, static_cast<hipStream_t>(stream)));
+    return SG_OK;
+}
+int sg_stream_create(void** stream) {
+    if (!stream) { set_error("null pointer"); return SG_ERR_ARG; }
+    hipStream_t s;
+    SG_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = s;
+    return SG_OK;
+}
+int sg_stream_destroy(void* stream) { if (stream) SG_HIP(hipStreamDestroy(static_cast<hipStream_t>(stream))); return SG_OK; }
+int sg_stream_sync(void* stream) { SG_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream))); return SG_OK; }
+
+int sg_plan_create(sg_plan** plan, int nperseg, int nfft, int hop, const double* window, int detrend, double fs,
+                   int scaling, int mode, int dtype) {
+    if (!plan || !window) { set_error("null pointer"); return SG_ERR_ARG; }
+    *plan = nullptr;
+    if (nperseg < 1) { set_error("nperseg must be a positive integer"); return SG_ERR_ARG; }
+    if (nfft < nperseg) { set_error("nfft must be greater than or equal to nperseg."); return SG_ERR_ARG; }
+    if (hop < 1 || hop > nperseg) { set_error("noverlap must be less than nperseg."); return SG_ERR_ARG; }
+    if (detrend < 0 || detrend > 2) { set_error("Trend type must be 'linear' or 'constant'."); return SG_ERR_ARG; }
+    if (scaling < 0 || scaling > 1) { set_error("Unknown scaling: %d", scaling); return SG_ERR_ARG; }
+    if (mode < 0 || mode > 3) { set_error("unknown value for mode %d", mode); return SG_ERR_ARG; }
+    if (dtype != SG_F32 && dtype != SG_F64) { set_error("bad dtype %d", dtype); return SG_ERR_ARG; }
+    if (!(fs > 0.0) || !std::isfinite(fs)) { set_error("fs must be positive and finite"); return SG_ERR_ARG; }
+
+    auto* p = new sg_plan();
+    p->nperseg = nperseg; p->nfft = nfft; p->hop = hop;
+    p->detrend = detrend; p->scaling = scaling; p->mode = mode; p->dtype = dtype; p->fs = fs;
+    hipError_t e = hipGetDevice(&p->device);
+    if (e != hipSuccess) { delete p; return hip_fail(e, "hipGetDevice"); }
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, p->device);
+    if (e != hipSuccess) { delete p; return hip_fail(e, "hipGetDeviceProperties"); }
+    p->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+
+    std::vector<double> w(window, window + nperseg);
+    int rc = dtype == SG_F64 ? build_common_tables<double>(*p, w) : build_common_tables<float>(*p, w);
+    if (rc == SG_OK) {
+        if (r8x3_ok(*p)) {
+            p->kernel = Kernel::R8X3;
+            rc = build_r8x3_tables(*p, w);
+        } else if (stockham_ok(*p)) {
+            p->kernel = Kernel::STOCKHAM;
+        } else {
+            p->kernel = Kernel::BLUESTEIN;
+            rc = build_bluestein_tables(*p);
+        }
+    }
+    if (rc != SG_OK) { free_tables(p); delete p; return rc; }
+    *plan = p;
+    return SG_OK;
+}
+
+int sg_plan_destroy(sg_plan* plan) {
+    if (!plan) return SG_OK;
+    free_tables(plan);
+    delete plan;
+    return SG_OK;
+}
+
+int sg_plan_n_frames(const sg_plan* plan, int64_t n_samples, int64_t* n_frames) {
+    if (!plan || !n_frames) { set_error("null pointer"); return SG_ERR_ARG; }
+    *n_frames = n_samples < plan->nperseg ? 0 : (n_samples - plan->nperseg) / plan->hop + 1;
+    return SG_OK;
+}
+
+int sg_plan_n_bins(const sg_plan* plan, int* n_bins) {
+    if (!plan || !n_bins) { set_error("null pointer"); return SG_ERR_ARG; }
+    *n_bins = plan->nfft / 2 + 1;
+    return SG_OK;
+}
+
+int sg_plan_scale(const sg_plan* plan, double* scale) {
+    if (!plan || !scale) { set_error("null pointer"); return SG_ERR_ARG; }
+    *scale = plan->scale;
+    return SG_OK;
+}
+
+const char* sg_plan_kernel(const sg_plan* plan) {
+    if (!plan) return "";
+    switch (plan->kernel) {
+        case Kernel::R8X3: return "r8x3";
+        case Kernel::STOCKHAM: return "stockham";
+        case Kernel::BLUESTEIN: return "bluestein";
+    }
+    return "";
+}
+
+int sg_plan_force_kernel(sg_plan* plan, const char* name) {
+    if (!plan || !name) { set_error("null pointer"); return SG_ERR_ARG; }
+    if (!strcmp(name, "r8x3")) {
+        if (!r8x3_ok(*plan)) { set_error("plan cannot run on r8x3"); return SG_ERR_UNSUPPORTED; }
+        if (!plan->r8_tw_dev) { std::vector<double> none; if (int rc = build_r8x3_tables(*plan, none)) return rc; }
+        plan->kernel = Kernel::R8X3;
+        return SG_OK;
+    }
+    if (!strcmp(name, "stockham")) {
+        if (!stockham_ok(*plan)) { set_error("plan cannot run on stockham"); return SG_ERR_UNSUPPORTED; }
+        plan->kernel = Kernel::STOCKHAM;
+        return SG_OK;
+    }
+    if (!strcmp(name, "bluestein")) {
+        if (!plan->bs_chirp_dev) { if (int rc = build_bluestein_tables(*plan)) return rc; }
+        plan->kernel = Kernel::BLUESTEIN;
+        return SG_OK;
+    }
+    set_error("unknown kernel family '%s'", name);
+    return SG_ERR_ARG;
+}
+
+// A7 -- must reproduce numpy's arithmetic exactly:
+//   rfftfreq(n, d): val = 1.0/(n*d); results = arange(0, n//2+1) * val         (scipy:2115, d = 1/fs)
+//   time = arange(nperseg/2, N - nperseg/2 + 1, step) / float(fs)              (scipy:2136-2137)
+// numpy's arange(start, stop, step) for doubles fills start + i*step.
+int sg_freqs(int nfft, double fs, double* f_out) {
+    if (!f_out || nfft < 1 || !(fs > 0)) { set_error("bad argument"); return SG_ERR_ARG; }
+    const double d = 1.0 / fs;
+    const double val = 1.0 / (static_cast<double>(nfft) * d);
+    for (int k = 0; k <= nfft / 2; ++k) f_out[k] = static_cast<double>(k) * val;
+    return SG_OK;
+}
+
+int sg_times(int64_t n_samples, int nperseg, int hop, double fs, double* t_out) {
+    if (nperseg < 1 || hop < 1 || !(fs > 0)) { set_error("bad argument"); return SG_ERR_ARG; }
+    if (n_samples < nperseg) return SG_OK;
+    if (!t_out) { set_error("null pointer"); return SG_ERR_ARG; }
+    const int64_t n = (n_samples - nperseg) / hop + 1;
+    const double start = static_cast<double>(nperseg) / 2.0;
+    // numpy arange: first two values are start and start+step, the rest start + i*delta with delta = (start+step)-start
+    const double delta = (start + static_cast<double>(hop)) - start;
+    for (int64_t i = 0; i < n; ++i) t_out[i] = (start + static_cast<double>(i) * delta) / fs;
+    return SG_OK;
+}
+
+int sg_stft(const sg_plan* plan, const void* x_dev, int64_t n_samples, int64_t clip_stride, int n_clips, void* out_dev,
+            int64_t out_clip_stride, void* stream) {
+    StftArgs a{};
+    a.x = x_dev; a.in_i16 = 0; a.n_samples = n_samples; a.clip_stride = clip_stride; a.n_clips = n_clips;
+    a.out = out_dev; a.out_clip_stride = out_clip_stride; a.stream = static_cast<hipStream_t>(stream);
+    return run_stft(plan, a);
+}
+
+int sg_stft_i16(const sg_plan* plan, const int16_t* x_dev, int64_t n_samples, int64_t clip_stride, int n_clips,
+                float* out_dev, int64_t out_clip_stride, void* stream) {
+    if (plan && plan->dtype != SG_F32) { set_error("int16 input needs an f32 plan"); return SG_ERR_ARG; }
+    if (plan && plan->kernel == Kernel::BLUESTEIN) { set_error("int16 input is not wired to the Bluestein path"); return SG_ERR_UNSUPPORTED; }
+    StftArgs a{};
+    a.x = x_dev; a.in_i16 = 1; a.n_samples = n_samples; a.clip_stride = clip_stride; a.n_clips = n_clips;
+    a.out = out_dev; a.out_clip_stride = out_clip_stride; a.stream = static_cast<hipStream_t>(stream);
+    return run_stft(plan, a);
+}
+
+int sg_stft_band_power(const sg_plan* plan, const void* x_dev, int64_t n_samples, int64_t clip_stride, int n_clips,
+                       int k_lo, int k_hi, void* band_out_dev, int64_t out_clip_stride, void* stream) {
+    if (plan && plan->kernel == Kernel::BLUESTEIN) { set_error("fused band power is not wired to the Bluestein path"); return SG_ERR_UNSUPPORTED; }
+    StftArgs a{};
+    a.x = x_dev; a.in_i16 = 0; a.n_samples = n_samples; a.clip_stride = clip_stride; a.n_clips = n_clips;
+    a.out = band_out_dev; a.out_clip_stride = out_clip_stride; a.band_mode = 1; a.k_lo = k_lo; a.k_hi = k_hi;
+    a.stream = static_cast<hipStream_t>(stream);
+    return run_stft(plan, a);
+}
+
+int sg_time_stft(const sg_plan* plan, const void* x_dev, int64_t n_samples, int64_t clip_stride, int n_clips,
+                 void* out_dev, int64_t out_clip_stride, void* stream, int iters, float* ms_per_launch) {
+    if (!ms_per_launch || iters < 1) { set_error("bad argument"); return SG_ERR_ARG; }
+    auto s = static_cast<hipStream_t>(stream);
+    hipEvent_t e0, e1;
+    SG_HIP(hipEventCreate(&e0));
+    SG_HIP(hipEventCreate(&e1));
+    int rc = SG_OK;
+    SG_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < iters && rc == SG_OK; ++i)
+        rc = sg_stft(plan, x_dev, n_samples, clip_stride, n_clips, out_dev, out_clip_stride, stream);
+    SG_HIP(hipEventRecord(e1, s));
+    SG_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    SG_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_per_launch = ms / static_cast<float>(iters);
+    return rc;
+}
+
+}  // extern "C"

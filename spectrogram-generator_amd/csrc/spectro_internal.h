@@ -1,0 +1,65 @@
+// Internal declarations shared by the translation units of libspectro.so.
+// Not part of the ABI (that is include/spectro.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "spectro.h"
+
+namespace sg {
+
+// thread-local error plumbing -------------------------------------------------
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);   // records message, returns SG_ERR_HIP
+
+#define SG_HIP(call)                                                   \
+    do {                                                               \
+        hipError_t e__ = (call);                                       \
+        if (e__ != hipSuccess) return ::sg::hip_fail(e__, #call);      \
+    } while (0)
+
+enum class Kernel { R8X3, STOCKHAM, BLUESTEIN };
+
+}  // namespace sg
+
+// The plan: argument triage done once, device tables owned here.
+struct sg_plan {
+    int nperseg = 0, nfft = 0, hop = 0;
+    int detrend = 0, scaling = 0, mode = 0, dtype = 0;
+    double fs = 1.0;
+    double scale = 1.0;          // 1/(fs*sum w^2) or 1/(sum w)^2, in dtype precision (scipy:2086-2089)
+    sg::Kernel kernel = sg::Kernel::STOCKHAM;
+    int device = 0;
+    int n_cu = 256;
+    // device tables
+    void* win_dev = nullptr;     // nperseg reals of dtype
+    void* tw_dev = nullptr;      // nfft/2 complex of dtype: exp(-2*pi*i*k/nfft), k < nfft/2
+    void* r8_tw_dev = nullptr;   // R8X3 only: [18][64] float2 per-lane twiddles
+    // Bluestein tables (complex of dtype)
+    int bs_len = 0;              // padded pow2 length L >= 2*nfft-1
+    void* bs_chirp_dev = nullptr;   // b[n] = exp(-i*pi*n^2/nfft), n < nfft
+    void* bs_filter_dev = nullptr;  // FFT_L of conj-chirp filter, bit-reversed order, pre-scaled by 1/L
+    void* bs_tw_dev = nullptr;      // exp(-2*pi*i*k/L), k < L/2
+};
+
+namespace sg {
+
+// launchers (each returns an sg_status) ---------------------------------------
+struct StftArgs {
+    const void* x; int in_i16;              // input pointer; 1 = int16 samples
+    int64_t n_samples, clip_stride; int n_clips;
+    void* out; int64_t out_clip_stride;     // spectrum out (may be null for band mode)
+    int64_t n_frames;
+    int band_mode, k_lo, k_hi;              // band-power variant: only per-frame sums are written
+    hipStream_t stream;
+};
+
+int launch_r8x3(const sg_plan& p, const StftArgs& a);
+int launch_stockham(const sg_plan& p, const StftArgs& a);
+int launch_bluestein(const sg_plan& p, const StftArgs& a);
+
+int build_r8x3_tables(sg_plan& p, const std::vector<double>& window);
+int build_bluestein_tables(sg_plan& p);
+
+}  // namespace sg

@@ -1,0 +1,361 @@
+// stft_r8x3.hip -- the headline kernel: fused STFT -> one-sided PSD for nperseg = nfft = 1024, f32.
+//
+// Replaces, per frame, scipy's _fft_helper + PSD epilogue
+// (scipy/signal/_spectral_py.py:2180-2202 framing/detrend/window/rfft, :2125-2134 |X|^2*scale
+// with interior bins doubled) as called from the reference at PlotEngine.py:113 / :232.
+//
+// CDNA4 mapping (gfx950, wave64):
+//   * one wavefront owns one frame at a time and walks FPW consecutive frames of one clip, so the
+//     hop-overlapped samples of neighbouring frames are L1/L2 hits and HBM sees each sample once;
+//   * the real 1024-point FFT is a 512-point complex FFT of z[n] = x[2n] + i*x[2n+1] (even/odd packing)
+//     followed by a split pass.  512 = 8*8*8: every lane keeps 8 complex values in VGPRs and runs three
+//     register-resident radix-8 butterflies; the two transposes in between and the k <-> 512-k pairing of the
+//     split pass go through a 4.5 KiB per-wave LDS slab with padded strides (72 / 66 / 1 elements) that
+//     make every ds_write_b64 / ds_read_b64 bank-conflict free (checked by tools/sim_r8x3.py);
+//   * a wave only ever talks to its own slab, so there is not a single s_barrier in the kernel;
+//   * window (16 floats/lane) and all twiddles (18 complex/lane) are loaded once per wave into VGPRs;
+//   * the epilogue computes |X|^2 * scale (x2 for interior bins) and streams 513 contiguous floats per
+//     frame; the spectrum is never staged in HBM in complex form.
+//
+// Algorithmic HBM bytes per frame: hop*4 read + 513*4 written (3076 B at hop = 256).
+#include "spectro_internal.h"
+
+#include <cmath>
+
+namespace sg {
+namespace {
+
+constexpr int kN = 1024;        // samples per frame
+constexpr int kM = 512;         // complex points
+constexpr int kBins = 513;
+constexpr int kS1 = 72;         // LDS stride (elements) of exchange 1: [b][l2]
+constexpr int kS2 = 66;         // LDS stride of exchange 2: [j0][l3]
+constexpr int kSlab = 8 * kS1;  // 576 complex = 4608 B per wave
+constexpr int kWavesPerWg = 4;
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 w) {
+    return make_float2(fmaf(a.x, w.x, -a.y * w.y), fmaf(a.x, w.y, a.y * w.x));
+}
+// multiply by -i
+__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }
+
+// In-register 8-point DFT, forward sign, natural order in and out:
+// a[r] <- sum_k a[k] * exp(-2*pi*i*k*r/8).
+__device__ __forceinline__ void radix8(float2 (&a)[8]) {
+    constexpr float h = 0.70710678118654752440f;
+    const float2 b0 = cadd(a[0], a[4]), b4 = csub(a[0], a[4]);
+    const float2 b1 = cadd(a[1], a[5]), b5 = csub(a[1], a[5]);
+    const float2 b2 = cadd(a[2], a[6]), b6 = csub(a[2], a[6]);
+    const float2 b3 = cadd(a[3], a[7]), b7 = csub(a[3], a[7]);
+    const float2 t5 = make_float2((b5.x + b5.y) * h, (b5.y - b5.x) * h);     // * w8
+    const float2 t6 = mul_mi(b6);                                            // * w8^2
+    const float2 t7 = make_float2((b7.y - b7.x) * h, -(b7.x + b7.y) * h);    // * w8^3
+    const float2 c0 = cadd(b0, b2), c2 = csub(b0, b2);
+    const float2 c1 = cadd(b1, b3), c3 = mul_mi(csub(b1, b3));
+    const float2 c4 = cadd(b4, t6), c6 = csub(b4, t6);
+    const float2 c5 = cadd(t5, t7), c7 = mul_mi(csub(t5, t7));
+    a[0] = cadd(c0, c1); a[4] = csub(c0, c1);
+    a[2] = cadd(c2, c3); a[6] = csub(c2, c3);
+    a[1] = cadd(c4, c5); a[5] = csub(c4, c5);
+    a[3] = cadd(c6, c7); a[7] = csub(c6, c7);
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+
+// Sum over the 64 lanes, result in every lane.  DPP butterflies inside a row of 16, readlane across rows.
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_mov<0xB1>(v);     // quad_perm [1,0,3,2]  (lane ^ 1)
+    v += dpp_mov<0x4E>(v);     // quad_perm [2,3,0,1]  (lane ^ 2)
+    v += dpp_mov<0x141>(v);    // row_half_mirror      (the other quad of each 8)
+    v += dpp_mov<0x140>(v);    // row_mirror           (the other 8 of each 16)
+    const int iv = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+// Orders this wave's LDS writes before its following LDS reads for the compiler; the hardware
+// executes one wave's DS operations in issue order, so no s_barrier / s_waitcnt is needed.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <typename TIn, bool ALIGNED>
+__device__ __forceinline__ float2 load_pair(const TIn* p);
+
+template <>
+__device__ __forceinline__ float2 load_pair<float, true>(const float* p) {
+    return *reinterpret_cast<const float2*>(p);
+}
+template <>
+__device__ __forceinline__ float2 load_pair<float, false>(const float* p) {
+    return make_float2(p[0], p[1]);
+}
+template <>
+__device__ __forceinline__ float2 load_pair<int16_t, true>(const int16_t* p) {
+    const short2 s = *reinterpret_cast<const short2*>(p);
+    return make_float2(static_cast<float>(s.x), static_cast<float>(s.y));
+}
+template <>
+__device__ __forceinline__ float2 load_pair<int16_t, false>(const int16_t* p) {
+    return make_float2(static_cast<float>(p[0]), static_cast<float>(p[1]));
+}
+
+// Workgroups b and b+8 share an XCD (round-robin dispatch); hand each XCD a contiguous run of
+// chunk groups so that the (nperseg - hop)-sample halo between neighbouring chunks is an L2 hit.
+// Bijective for any grid size (see guide T1).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+struct R8Params {
+    const void* x;
+    int64_t clip_stride;
+    int n_frames;          // per clip
+    int hop;
+    int fpw;               // frames per wave-chunk
+    int chunks_per_clip;
+    int total_chunks;
+    float* out;            // [clip][frame][513]   (MODE psd / magnitude)
+    int64_t out_clip_stride;
+    const float2* win2;    // [512]  (w[2n], w[2n+1])
+    const float2* tw;      // [18][64]
+    float scale;
+    int k_lo, k_hi;        // BAND only
+};
+
+// MODE: 0 = psd, 1 = magnitude.  BAND: write only sum_{k_lo..k_hi} per frame.
+template <typename TIn, bool ALIGNED, bool DETREND, int MODE, bool BAND>
+__global__ __launch_bounds__(64 * kWavesPerWg) void stft1024_r8x3_kernel(const R8Params p) {
+    __shared__ __attribute__((aligned(16))) float2 lds[kWavesPerWg * kSlab];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float2* const buf = lds + wave * kSlab;
+
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int chunk = wg * kWavesPerWg + wave;
+    if (chunk >= p.total_chunks) return;          // wave-uniform, and the kernel has no barriers
+    const int clip = chunk / p.chunks_per_clip;
+    const int f0 = (chunk - clip * p.chunks_per_clip) * p.fpw;
+    const int f1 = min(f0 + p.fpw, p.n_frames);
+
+    // ---- per-wave constants -------------------------------------------------
+    float2 w[8], t1[7], t2[7], t3[4];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) w[a] = p.win2[lane + 64 * a];
+#pragma unroll
+    for (int r = 0; r < 7; ++r) t1[r] = p.tw[r * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < 7; ++r) t2[r] = p.tw[(7 + r) * 64 + lane];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) t3[m] = p.tw[(14 + m) * 64 + lane];
+
+    const int j0 = lane & 7, hi = lane >> 3;
+    float2* const x1w = buf + hi * kS1 + j0;        // + 8*r
+    float2* const x1r = buf + lane;                 // + b*kS1
+    float2* const x2w = buf + j0 * kS2 + hi;        // + 8*s
+    float2* const x2r = buf + lane;                 // + j0*kS2
+    float2* const x3w = buf + lane;                 // + 64*t
+    const float2* const x3a = buf + lane;           // + 64*m
+    const float2* const x3b = buf + (kM - lane);    // - 64*m
+
+    const TIn* const xclip = static_cast<const TIn*>(p.x) + static_cast<int64_t>(clip) * p.clip_stride + 2 * lane;
+    float* const oclip = BAND ? nullptr : p.out + static_cast<int64_t>(clip) * p.out_clip_stride;
+
+    const float q_in = MODE == 0 ? p.scale * 0.5f : p.scale * 0.25f;     // interior bins (psd: doubled)
+    const float q_edge = p.scale * 0.25f;                                // bins 0 and 512
+    const float q0 = lane == 0 ? q_edge : q_in;
+
+    for (int f = f0; f < f1; ++f) {
+        const TIn* const src = xclip + static_cast<int64_t>(f) * p.hop;
+        float2 a[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = load_pair<TIn, ALIGNED>(src + 128 * k);
+
+        if (DETREND) {   // A3: subtract the frame mean (scipy:2191, detrend type 'constant')
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += a[k].x + a[k].y;
+            const float mean = wave_sum(s) * (1.0f / kN);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { a[k].x -= mean; a[k].y -= mean; }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { a[k].x *= w[k].x; a[k].y *= w[k].y; }   // A4 window
+
+        // ---- pass 1: DFT over a (stride-64 elements), twiddle w512^(lane*r)
+        radix8(a);
+#pragma unroll
+        for (int r = 1; r < 8; ++r) a[r] = cmul(a[r], t1[r - 1]);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) x1w[8 * r] = a[r];
+        wave_lds_fence();
+#pragma unroll
+        for (int b = 0; b < 8; ++b) a[b] = x1r[b * kS1];
+        wave_lds_fence();
+
+        // ---- pass 2: lane = j0 + 8r, DFT over b, twiddle w64^(j0*s)
+        radix8(a);
+#pragma unroll
+        for (int s = 1; s < 8; ++s) a[s] = cmul(a[s], t2[s - 1]);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) x2w[8 * s] = a[s];
+        wave_lds_fence();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = x2r[j * kS2];
+        wave_lds_fence();
+
+        // ---- pass 3: lane = r + 8s, DFT over j0 -> Z[lane + 64t]
+        radix8(a);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) x3w[64 * t] = a[t];
+        if (lane == 0) buf[kM] = a[0];              // Z[512] := Z[0] closes the k <-> 512-k pairing
+        wave_lds_fence();
+
+        // ---- split pass + |X|^2 epilogue (A5 tail + A6) ----------------------
+        float* const orow = BAND ? nullptr : oclip + static_cast<int64_t>(f) * kBins;
+        float band = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const float2 A = x3a[64 * m];
+            const float2 B = x3b[-64 * m];                      // Z[512-k]; conj applied below
+            const float2 S = make_float2(A.x + B.x, A.y - B.y); // A + conj(B)
+            const float2 D = make_float2(A.x - B.x, A.y + B.y); // A - conj(B)
+            const float c = t3[m].x, s = t3[m].y;               // cos, sin of 2*pi*k/1024
+            const float2 T = make_float2(fmaf(s, D.x, -c * D.y), fmaf(c, D.x, s * D.y));   // i*W^k*D
+            const float2 Xk = csub(S, T), Xm = cadd(S, T);      // 2*X[k], 2*conj(X[512-k])
+            const float q = m == 0 ? q0 : q_in;
+            float pk = fmaf(Xk.x, Xk.x, Xk.y * Xk.y) * q;
+            float pm = fmaf(Xm.x, Xm.x, Xm.y * Xm.y) * q;
+            if (MODE == 1) { pk = sqrtf(pk); pm = sqrtf(pm); }
+            const int k = lane + 64 * m;
+            if (BAND) {
+                band += (k >= p.k_lo && k <= p.k_hi) ? pk : 0.f;
+                band += (kM - k >= p.k_lo && kM - k <= p.k_hi) ? pm : 0.f;
+            } else {
+                orow[k] = pk;
+                orow[kM - k] = pm;
+            }
+        }
+        {   // k = 256 pairs with itself: X[256] = conj(Z[256])
+            const float2 Zq = buf[256];
+            float pq = fmaf(Zq.x, Zq.x, Zq.y * Zq.y) * (q_in * 4.0f);
+            if (MODE == 1) pq = sqrtf(pq);
+            if (BAND) {
+                band += (lane == 0 && 256 >= p.k_lo && 256 <= p.k_hi) ? pq : 0.f;
+            } else if (lane == 0) {
+                orow[256] = pq;
+            }
+        }
+        if (BAND) {
+            const float tot = wave_sum(band);
+            if (lane == 0) p.out[static_cast<int64_t>(clip) * p.out_clip_stride + f] = tot;
+        }
+        wave_lds_fence();    // next frame's exchange-1 writes stay behind these reads
+    }
+}
+
+template <typename TIn, bool ALIGNED, bool DETREND, int MODE, bool BAND>
+int launch_one(const R8Params& prm, int n_wg, hipStream_t stream) {
+    hipLaunchKernelGGL((stft1024_r8x3_kernel<TIn, ALIGNED, DETREND, MODE, BAND>), dim3(n_wg), dim3(64 * kWavesPerWg), 0,
+                       stream, prm);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "stft1024_r8x3 launch");
+    return SG_OK;
+}
+
+template <typename TIn, bool ALIGNED, bool DETREND>
+int launch_mode(const R8Params& prm, int n_wg, hipStream_t s, int mode, bool band) {
+    if (band) return launch_one<TIn, ALIGNED, DETREND, 0, true>(prm, n_wg, s);
+    if (mode == SG_MODE_PSD) return launch_one<TIn, ALIGNED, DETREND, 0, false>(prm, n_wg, s);
+    return launch_one<TIn, ALIGNED, DETREND, 1, false>(prm, n_wg, s);
+}
+
+template <typename TIn>
+int launch_in(const R8Params& prm, int n_wg, hipStream_t s, bool aligned, bool detrend, int mode, bool band) {
+    if (aligned) {
+        return detrend ? launch_mode<TIn, true, true>(prm, n_wg, s, mode, band)
+                       : launch_mode<TIn, true, false>(prm, n_wg, s, mode, band);
+    }
+    return detrend ? launch_mode<TIn, false, true>(prm, n_wg, s, mode, band)
+                   : launch_mode<TIn, false, false>(prm, n_wg, s, mode, band);
+}
+
+}  // namespace
+
+// Frames per wave-chunk: long enough to amortise the per-wave constant loads and to keep the overlap
+// reads in L1/L2, short enough that the grid stays several times larger than the chip.
+static int pick_fpw(int64_t n_frames, int n_clips, int n_cu) {
+    const int64_t total = n_frames * n_clips;
+    int fpw = 16;
+    while (fpw > 1 && (total + fpw - 1) / fpw < static_cast<int64_t>(n_cu) * 5 * kWavesPerWg * 4) fpw >>= 1;
+    return fpw;
+}
+
+int launch_r8x3(const sg_plan& p, const StftArgs& a) {
+    if (a.n_frames <= 0 || a.n_clips <= 0) return SG_OK;
+    if (a.n_frames > INT32_MAX) { set_error("r8x3: more than 2^31 frames per clip"); return SG_ERR_ARG; }
+    R8Params prm{};
+    prm.x = a.x;
+    prm.clip_stride = a.clip_stride;
+    prm.n_frames = static_cast<int>(a.n_frames);
+    prm.hop = p.hop;
+    prm.fpw = pick_fpw(a.n_frames, a.n_clips, p.n_cu);
+    prm.chunks_per_clip = static_cast<int>((a.n_frames + prm.fpw - 1) / prm.fpw);
+    const int64_t total = static_cast<int64_t>(prm.chunks_per_clip) * a.n_clips;
+    if (total > INT32_MAX) { set_error("r8x3: too many chunks"); return SG_ERR_ARG; }
+    prm.total_chunks = static_cast<int>(total);
+    prm.out = static_cast<float*>(a.out);
+    prm.out_clip_stride = a.out_clip_stride;
+    prm.win2 = static_cast<const float2*>(p.win_dev);
+    prm.tw = static_cast<const float2*>(p.r8_tw_dev);
+    prm.scale = static_cast<float>(p.scale);
+    prm.k_lo = a.k_lo;
+    prm.k_hi = a.k_hi;
+    const int n_wg = (prm.total_chunks + kWavesPerWg - 1) / kWavesPerWg;
+    const bool detrend = p.detrend == SG_DETREND_CONSTANT;
+    if (a.in_i16) {
+        const bool aligned = (p.hop % 2 == 0) && (a.clip_stride % 2 == 0) && (reinterpret_cast<uintptr_t>(a.x) % 4 == 0);
+        return launch_in<int16_t>(prm, n_wg, a.stream, aligned, detrend, p.mode, a.band_mode != 0);
+    }
+    const bool aligned = (p.hop % 2 == 0) && (a.clip_stride % 2 == 0) && (reinterpret_cast<uintptr_t>(a.x) % 8 == 0);
+    return launch_in<float>(prm, n_wg, a.stream, aligned, detrend, p.mode, a.band_mode != 0);
+}
+
+// Per-lane twiddle table [18][64] (float2), computed in double:
+//   rows 0..6   t1[r-1][j]  = exp(-2*pi*i*j*r/512)            r = 1..7, j  = lane
+//   rows 7..13  t2[s-1][j]  = exp(-2*pi*i*(j&7)*s/64)         s = 1..7
+//   rows 14..17 t3[m][j]    = (cos, sin)(2*pi*(j+64m)/1024)   m = 0..3
+int build_r8x3_tables(sg_plan& p, const std::vector<double>& /*window*/) {
+    std::vector<float2> tw(18 * 64);
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int j = 0; j < 64; ++j) {
+        for (int r = 1; r < 8; ++r) {
+            const double ang = -two_pi * static_cast<double>((j * r) % 512) / 512.0;
+            tw[(r - 1) * 64 + j] = make_float2(static_cast<float>(std::cos(ang)), static_cast<float>(std::sin(ang)));
+            const double ang2 = -two_pi * static_cast<double>(((j & 7) * r) % 64) / 64.0;
+            tw[(7 + r - 1) * 64 + j] = make_float2(static_cast<float>(std::cos(ang2)), static_cast<float>(std::sin(ang2)));
+        }
+        for (int m = 0; m < 4; ++m) {
+            const double ang = two_pi * static_cast<double>(j + 64 * m) / 1024.0;
+            tw[(14 + m) * 64 + j] = make_float2(static_cast<float>(std::cos(ang)), static_cast<float>(std::sin(ang)));
+        }
+    }
+    SG_HIP(hipMalloc(&p.r8_tw_dev, tw.size() * sizeof(float2)));
+    SG_HIP(hipMemcpy(p.r8_tw_dev, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
+    return SG_OK;
+}
+
+}  // namespace sg

@@ -1,0 +1,254 @@
+// stft_stockham.hip -- general STFT kernel: any nperseg <= nfft = 2^q (2 <= nfft <= 8192), f32 or f64,
+// every detrend / scaling / mode of scipy.signal.spectrogram for real one-sided input.
+//
+// Same algorithm as the reference's call chain (scipy/signal/_spectral_py.py:2180-2202 and :2125-2134),
+// organised for a workgroup instead of a wavefront: a group of TPF threads owns one frame in LDS,
+//   load -> (sum x, sum u*x) -> detrend (none | constant | linear) -> window -> zero pad
+//   -> nfft/2-point complex Stockham radix-2 autosort FFT on the even/odd packed signal
+//   -> split pass -> |X|^2*scale (one-sided doubling) | |X| | X | arg X -> HBM.
+// Small transforms pack several frames into one 256-thread workgroup.  The r8x3 kernel
+// (stft_r8x3.hip) is the fast path for the headline size; this kernel is the correctness net for
+// everything else and the building block of the Bluestein path.
+#include "spectro_internal.h"
+
+namespace sg {
+namespace {
+
+constexpr int kThreads = 256;
+
+template <typename T> struct Cx { T x, y; };
+
+template <typename T> __device__ __forceinline__ T t_sqrt(T v);
+template <> __device__ __forceinline__ float t_sqrt<float>(float v) { return sqrtf(v); }
+template <> __device__ __forceinline__ double t_sqrt<double>(double v) { return sqrt(v); }
+template <typename T> __device__ __forceinline__ T t_atan2(T y, T x);
+template <> __device__ __forceinline__ float t_atan2<float>(float y, float x) { return atan2f(y, x); }
+template <> __device__ __forceinline__ double t_atan2<double>(double y, double x) { return atan2(y, x); }
+
+template <typename T>
+struct GenParams {
+    const void* x;            // TIn samples
+    int64_t clip_stride;
+    int64_t n_frames;         // per clip
+    int64_t total_frames;     // n_frames * n_clips
+    int nperseg, nfft, hop, log2m;
+    int tpf;                  // threads per frame (power of two, <= 256)
+    int detrend, mode;
+    T* out;
+    int64_t out_clip_stride;
+    const T* win;             // [nperseg]
+    const Cx<T>* tw;          // [nfft/2]  exp(-2*pi*i*k/nfft)
+    T scale;                  // psd scale (already sqrt'ed for the non-psd modes)
+    int band_mode, k_lo, k_hi;
+};
+
+template <typename T, typename TIn>
+__global__ __launch_bounds__(kThreads) void stft_stockham_kernel(const GenParams<T> p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int M = p.nfft >> 1;
+    const int tpf = p.tpf;
+    const int groups = kThreads / tpf;
+    const int g = threadIdx.x / tpf;
+    const int tid = threadIdx.x - g * tpf;
+
+    // LDS carve: per group two complex buffers of M (= nfft reals each), then the reduction scratch
+    const size_t buf_elems = static_cast<size_t>(p.nfft);            // reals per buffer
+    T* const base = reinterpret_cast<T*>(smem_raw);
+    T* bufA = base + static_cast<size_t>(g) * 2 * buf_elems;
+    T* bufB = bufA + buf_elems;
+    double* const red = reinterpret_cast<double*>(base + static_cast<size_t>(groups) * 2 * buf_elems) + static_cast<size_t>(g) * 2 * tpf;
+
+    const int nbins = M + 1;
+    const int n = p.nperseg;
+
+    for (int64_t fbase = static_cast<int64_t>(blockIdx.x) * groups; fbase < p.total_frames;
+         fbase += static_cast<int64_t>(gridDim.x) * groups) {
+        const int64_t fr = fbase + g;
+        const bool active = fr < p.total_frames;
+        const int64_t clip = active ? fr / p.n_frames : 0;
+        const int64_t f = active ? fr - clip * p.n_frames : 0;
+        const TIn* src = static_cast<const TIn*>(p.x) + clip * p.clip_stride + f * p.hop;
+
+        // ---- load + partial sums (A2, A3) -----------------------------------
+        double s0 = 0.0, s1 = 0.0;
+        if (active) {
+            for (int i = tid; i < p.nfft; i += tpf) {
+                T v = T(0);
+                if (i < n) {
+                    v = static_cast<T>(src[i]);
+                    s0 += static_cast<double>(v);
+                    s1 += static_cast<double>(v) * static_cast<double>(i + 1);
+                }
+                bufA[i] = v;
+            }
+        }
+        T c0 = T(0), c1 = T(0);    // trend = c0 + c1 * (i+1)/n
+        if (p.detrend != SG_DETREND_NONE) {
+            red[tid] = s0;
+            red[tpf + tid] = s1;
+            __syncthreads();
+            for (int s = tpf >> 1; s > 0; s >>= 1) {
+                if (tid < s) {
+                    red[tid] += red[tid + s];
+                    red[tpf + tid] += red[tpf + tid + s];
+                }
+                __syncthreads();
+            }
+            const double sx = red[0], sux = red[tpf] / n;     // u_i = (i+1)/n
+            if (p.detrend == SG_DETREND_CONSTANT) {
+                c0 = static_cast<T>(sx / n);
+            } else {
+                // least squares line through (u_i, x_i): x ~ beta*u + alpha
+                const double dn = n;
+                const double su = (dn + 1.0) * 0.5;                              // sum u
+                const double suu = (dn + 1.0) * (2.0 * dn + 1.0) / (6.0 * dn);   // sum u^2
+                const double den = dn * suu - su * su;
+                const double beta = den != 0.0 ? (dn * sux - su * sx) / den : 0.0;
+                const double alpha = (sx - beta * su) / dn;
+                c0 = static_cast<T>(alpha);
+                c1 = static_cast<T>(beta / dn);
+            }
+            __syncthreads();     // red is reused by the next frame
+        } else {
+            __syncthreads();
+        }
+
+        // ---- detrend + window (A3, A4), in place; bufA viewed as M complex ----
+        if (active) {
+            for (int i = tid; i < n; i += tpf) {
+                const T v = bufA[i] - (c0 + c1 * static_cast<T>(i + 1));
+                bufA[i] = v * p.win[i];
+            }
+        }
+        __syncthreads();
+
+        // ---- M-point complex Stockham radix-2 FFT (A5) ------------------------
+        Cx<T>* src_c = reinterpret_cast<Cx<T>*>(bufA);
+        Cx<T>* dst_c = reinterpret_cast<Cx<T>*>(bufB);
+        const int half = M >> 1;
+        for (int st = 0; st < p.log2m; ++st) {
+            const int pp = 1 << st;
+            if (active) {
+                for (int i = tid; i < half; i += tpf) {
+                    const int k = i & (pp - 1);
+                    const int j = ((i - k) << 1) + k;
+                    const Cx<T> w = p.tw[static_cast<size_t>(k) * (M >> st)];   // exp(-i*pi*k/pp)
+                    const Cx<T> u0 = src_c[i];
+                    const Cx<T> v = src_c[i + half];
+                    const Cx<T> u1 = {v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x};
+                    dst_c[j] = {u0.x + u1.x, u0.y + u1.y};
+                    dst_c[j + pp] = {u0.x - u1.x, u0.y - u1.y};
+                }
+            }
+            __syncthreads();
+            Cx<T>* t = src_c; src_c = dst_c; dst_c = t;
+        }
+        const Cx<T>* Z = src_c;
+
+        // ---- split pass + epilogue (A6) ---------------------------------------
+        double bsum = 0.0;
+        if (active) {
+            const int64_t row = clip * p.out_clip_stride +
+                                f * (p.mode == SG_MODE_COMPLEX ? 2 * static_cast<int64_t>(nbins) : nbins);
+            for (int k = tid; k < nbins; k += tpf) {
+                const Cx<T> A = Z[k == M ? 0 : k];
+                const Cx<T> Bz = Z[(M - k) == M ? 0 : (M - k)];
+                const T sx = A.x + Bz.x, sy = A.y - Bz.y;      // A + conj(B)
+                const T dx = A.x - Bz.x, dy = A.y + Bz.y;      // A - conj(B)
+                Cx<T> w;
+                if (k == M) { w.x = T(-1); w.y = T(0); } else { w = p.tw[k]; }
+                // X = (S - i*W*D)/2 ; i*W*D = i*(wx*dx - wy*dy + i*(wx*dy + wy*dx))
+                const T tx = -(w.x * dy + w.y * dx), ty = w.x * dx - w.y * dy;
+                const T xr = T(0.5) * (sx - tx), xi = T(0.5) * (sy - ty);
+                if (p.mode == SG_MODE_PSD) {
+                    T v = (xr * xr + xi * xi) * p.scale;
+                    if (k != 0 && k != M) v *= T(2);
+                    if (p.band_mode) {
+                        if (k >= p.k_lo && k <= p.k_hi) bsum += static_cast<double>(v);
+                    } else {
+                        p.out[row + k] = v;
+                    }
+                } else if (p.mode == SG_MODE_MAGNITUDE) {
+                    p.out[row + k] = t_sqrt<T>(xr * xr + xi * xi) * p.scale;
+                } else if (p.mode == SG_MODE_COMPLEX) {
+                    p.out[row + 2 * k] = xr * p.scale;
+                    p.out[row + 2 * k + 1] = xi * p.scale;
+                } else {
+                    p.out[row + k] = t_atan2<T>(xi * p.scale, xr * p.scale);
+                }
+            }
+        }
+        if (p.band_mode) {
+            red[tid] = bsum;
+            __syncthreads();
+            for (int s = tpf >> 1; s > 0; s >>= 1) {
+                if (tid < s) red[tid] += red[tid + s];
+                __syncthreads();
+            }
+            if (active && tid == 0) p.out[clip * p.out_clip_stride + f] = static_cast<T>(red[0]);
+        }
+        __syncthreads();     // buffers are rewritten by the next frame
+    }
+}
+
+template <typename T, typename TIn>
+int launch_t(const sg_plan& p, const StftArgs& a) {
+    GenParams<T> prm{};
+    const int M = p.nfft / 2;
+    int log2m = 0;
+    while ((1 << log2m) < M) ++log2m;
+    prm.x = a.x;
+    prm.clip_stride = a.clip_stride;
+    prm.n_frames = a.n_frames;
+    prm.total_frames = a.n_frames * a.n_clips;
+    prm.nperseg = p.nperseg;
+    prm.nfft = p.nfft;
+    prm.hop = p.hop;
+    prm.log2m = log2m;
+    int tpf = M / 2;
+    if (tpf < 1) tpf = 1;
+    if (tpf > kThreads) tpf = kThreads;
+    prm.tpf = tpf;
+    prm.detrend = p.detrend;
+    prm.mode = p.mode;
+    prm.out = static_cast<T*>(a.out);
+    prm.out_clip_stride = a.out_clip_stride;
+    prm.win = static_cast<const T*>(p.win_dev);
+    prm.tw = static_cast<const Cx<T>*>(p.tw_dev);
+    prm.scale = static_cast<T>(p.mode == SG_MODE_PSD ? p.scale : std::sqrt(p.scale));
+    prm.band_mode = a.band_mode;
+    prm.k_lo = a.k_lo;
+    prm.k_hi = a.k_hi;
+
+    const int groups = kThreads / tpf;
+    const size_t lds = static_cast<size_t>(groups) * (2 * static_cast<size_t>(p.nfft) * sizeof(T) + 2 * tpf * sizeof(double));
+    if (lds > 160 * 1024) {
+        set_error("stockham: nfft=%d in %s needs %zu B of LDS (> 160 KiB)", p.nfft, sizeof(T) == 8 ? "f64" : "f32", lds);
+        return SG_ERR_UNSUPPORTED;
+    }
+    auto kern = stft_stockham_kernel<T, TIn>;
+    if (lds > 64 * 1024) {
+        SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   static_cast<int>(lds)));
+    }
+    int64_t n_wg = (prm.total_frames + groups - 1) / groups;
+    const int64_t cap = static_cast<int64_t>(p.n_cu) * 16;
+    if (n_wg > cap) n_wg = cap;
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(n_wg)), dim3(kThreads), lds, a.stream, prm);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "stft_stockham launch");
+    return SG_OK;
+}
+
+}  // namespace
+
+int launch_stockham(const sg_plan& p, const StftArgs& a) {
+    if (a.n_frames <= 0 || a.n_clips <= 0) return SG_OK;
+    if (p.dtype == SG_F64) {
+        if (a.in_i16) { set_error("int16 input needs an f32 plan"); return SG_ERR_ARG; }
+        return launch_t<double, double>(p, a);
+    }
+    return a.in_i16 ? launch_t<float, int16_t>(p, a) : launch_t<float, float>(p, a);
+}
+
+}  // namespace sg

@@ -1,0 +1,245 @@
+"""ctypes binding of libspectro.so (include/spectro.h) -- the only door to the device.
+
+There is NO CPU fallback: if the library is missing, cannot be loaded, or no gfx950
+device is visible, every compute entry point raises.  (The CPU oracle under oracle/
+is test infrastructure and is never imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PKG = os.path.dirname(_HERE)
+LIB_PATH = os.environ.get("SPECTRO_LIB", os.path.join(_PKG, "lib", "libspectro.so"))
+
+SG_OK, SG_ERR_ARG, SG_ERR_HIP, SG_ERR_UNSUPPORTED, SG_ERR_NO_DEVICE = 0, -1, -2, -3, -4
+DETREND = {False: 0, None: 0, "none": 0, "constant": 1, "c": 1, "linear": 2, "l": 2}
+SCALING = {"density": 0, "spectrum": 1}
+MODE = {"psd": 0, "magnitude": 1, "complex": 2, "angle": 3}
+F32, F64 = 0, 1
+
+_vp, _i, _i64, _d, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_size_t
+_pvp = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes); mirrors include/spectro.h declaration by declaration
+SIGNATURES = {
+    "sg_version": (_i, []),
+    "sg_last_error": (C.c_char_p, []),
+    "sg_device_count": (_i, [C.POINTER(_i)]),
+    "sg_init": (_i, [_i]),
+    "sg_device_info": (_i, [C.c_char_p, _sz, C.POINTER(_i), C.POINTER(C.c_uint64)]),
+    "sg_malloc": (_i, [_pvp, _sz]),
+    "sg_free": (_i, [_vp]),
+    "sg_host_alloc": (_i, [_pvp, _sz]),
+    "sg_host_free": (_i, [_vp]),
+    "sg_memcpy_h2d": (_i, [_vp, _vp, _sz, _vp]),
+    "sg_memcpy_d2h": (_i, [_vp, _vp, _sz, _vp]),
+    "sg_memset": (_i, [_vp, _i, _sz, _vp]),
+    "sg_stream_create": (_i, [_pvp]),
+    "sg_stream_destroy": (_i, [_vp]),
+    "sg_stream_sync": (_i, [_vp]),
+    "sg_plan_create": (_i, [_pvp, _i, _i, _i, C.POINTER(_d), _i, _d, _i, _i, _i]),
+    "sg_plan_destroy": (_i, [_vp]),
+    "sg_plan_n_frames": (_i, [_vp, _i64, C.POINTER(_i64)]),
+    "sg_plan_n_bins": (_i, [_vp, C.POINTER(_i)]),
+    "sg_plan_scale": (_i, [_vp, C.POINTER(_d)]),
+    "sg_plan_kernel": (C.c_char_p, [_vp]),
+    "sg_plan_force_kernel": (_i, [_vp, C.c_char_p]),
+    "sg_freqs": (_i, [_i, _d, C.POINTER(_d)]),
+    "sg_times": (_i, [_i64, _i, _i, _d, C.POINTER(_d)]),
+    "sg_stft": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _i64, _vp]),
+    "sg_stft_i16": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _i64, _vp]),
+    "sg_stft_band_power": (_i, [_vp, _vp, _i64, _i64, _i, _i, _i, _vp, _i64, _vp]),
+    "sg_minmax": (_i, [_vp, _i, _i64, _i, _i, _i, _vp, _vp]),
+    "sg_normalise_image": (_i, [_vp, _i, _i64, _i, _i, _i, _i, _d, _vp, _vp, _vp]),
+    "sg_band_features": (_i, [_vp, _i, _i64, _vp, _vp]),
+    "sg_band_sum": (_i, [_vp, _i, _i64, _i, _i, _i, _vp, _vp]),
+    "sg_band_totals": (_i, [_vp, _i, _i64, _i, _i, C.POINTER(_i), C.POINTER(_i), _vp, _vp]),
+    "sg_slice_bins": (_i, [_vp, _i, _i64, _i, _i, _i, _vp, _vp]),
+    "sg_time_stft": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _i64, _vp, _i, C.POINTER(C.c_float)]),
+}
+
+_lib = None
+_lock = threading.Lock()
+_device_ready = None
+
+
+class SpectroError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libspectro.so once; raises ImportError with build instructions if it is absent."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise ImportError(
+                        f"{LIB_PATH} not found: build it with `python spectrogram-generator_amd/build.py` "
+                        "(hipcc, gfx950).  There is no CPU fallback.")
+                L = C.CDLL(LIB_PATH)
+                for name, (res, args) in SIGNATURES.items():
+                    fn = getattr(L, name)       # AttributeError = header/library drift
+                    fn.restype, fn.argtypes = res, args
+                _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    return lib().sg_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int):
+    """Map sg_status to the exceptions the reference's GUI handlers expect."""
+    if rc == SG_OK:
+        return
+    msg = last_error()
+    if rc == SG_ERR_ARG:
+        raise ValueError(msg)
+    if rc == SG_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise SpectroError(f"libspectro status {rc}: {msg}")
+
+
+def ensure_device(device: int | None = None):
+    """Select the device (default: LOCAL_RANK or 0) and verify it is gfx950.  Raises if none."""
+    global _device_ready
+    if device is None:
+        if _device_ready is not None:
+            return _device_ready
+        device = int(os.environ.get("SPECTRO_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    check(lib().sg_init(int(device)))
+    _device_ready = int(device)
+    return _device_ready
+
+
+def device_info():
+    buf = C.create_string_buffer(64)
+    cu, mem = _i(0), C.c_uint64(0)
+    check(lib().sg_device_info(buf, 64, C.byref(cu), C.byref(mem)))
+    return {"arch": buf.value.decode(), "compute_units": cu.value, "hbm_bytes": mem.value}
+
+
+class DeviceBuffer:
+    """Owning handle of raw device memory obtained through sg_malloc."""
+
+    def __init__(self, nbytes: int):
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(lib().sg_malloc(C.byref(p), self.nbytes))
+        self.ptr = p.value
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            lib().sg_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def upload(self, arr, stream=None):
+        import numpy as np
+        a = np.ascontiguousarray(arr)
+        assert a.nbytes <= self.nbytes
+        check(lib().sg_memcpy_h2d(C.c_void_p(self.ptr), a.ctypes.data_as(C.c_void_p), a.nbytes, C.c_void_p(stream)))
+        return a   # keep alive until the stream is synchronised
+
+    def download(self, arr, stream=None, nbytes=None):
+        n = arr.nbytes if nbytes is None else nbytes
+        check(lib().sg_memcpy_d2h(arr.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr), n, C.c_void_p(stream)))
+        return arr
+
+
+def stream_sync(stream=None):
+    check(lib().sg_stream_sync(C.c_void_p(stream)))
+
+
+class Plan:
+    """RAII wrapper of sg_plan (argument triage + device tables for one nperseg/nfft/hop/window)."""
+
+    def __init__(self, nperseg, nfft, hop, window, detrend, fs, scaling, mode, dtype):
+        import numpy as np
+        ensure_device()
+        w = np.ascontiguousarray(window, dtype=np.float64)
+        if w.ndim != 1 or w.shape[0] != nperseg:
+            raise ValueError("window must be 1-D of length nperseg")
+        self.nperseg, self.nfft, self.hop = int(nperseg), int(nfft), int(hop)
+        self.dtype = int(dtype)
+        self.mode = int(mode)
+        h = C.c_void_p()
+        check(lib().sg_plan_create(C.byref(h), self.nperseg, self.nfft, self.hop,
+                                   w.ctypes.data_as(C.POINTER(_d)), int(detrend), float(fs), int(scaling),
+                                   int(mode), self.dtype))
+        self.handle = h
+
+    @property
+    def n_bins(self):
+        return self.nfft // 2 + 1
+
+    @property
+    def kernel(self):
+        return lib().sg_plan_kernel(self.handle).decode()
+
+    @property
+    def scale(self):
+        v = _d(0)
+        check(lib().sg_plan_scale(self.handle, C.byref(v)))
+        return v.value
+
+    def force_kernel(self, name: str):
+        check(lib().sg_plan_force_kernel(self.handle, name.encode()))
+
+    def n_frames(self, n_samples: int) -> int:
+        if n_samples < self.nperseg:
+            return 0
+        return (int(n_samples) - self.nperseg) // self.hop + 1
+
+    def stft(self, x_ptr, n_samples, clip_stride, n_clips, out_ptr, out_clip_stride, stream=None, int16=False):
+        fn = lib().sg_stft_i16 if int16 else lib().sg_stft
+        check(fn(self.handle, C.c_void_p(x_ptr), int(n_samples), int(clip_stride), int(n_clips),
+                 C.c_void_p(out_ptr), int(out_clip_stride), C.c_void_p(stream)))
+
+    def band_power(self, x_ptr, n_samples, clip_stride, n_clips, k_lo, k_hi, out_ptr, out_clip_stride, stream=None):
+        check(lib().sg_stft_band_power(self.handle, C.c_void_p(x_ptr), int(n_samples), int(clip_stride), int(n_clips),
+                                       int(k_lo), int(k_hi), C.c_void_p(out_ptr), int(out_clip_stride),
+                                       C.c_void_p(stream)))
+
+    def time_stft(self, x_ptr, n_samples, clip_stride, n_clips, out_ptr, out_clip_stride, iters, stream=None):
+        ms = C.c_float(0)
+        check(lib().sg_time_stft(self.handle, C.c_void_p(x_ptr), int(n_samples), int(clip_stride), int(n_clips),
+                                 C.c_void_p(out_ptr), int(out_clip_stride), C.c_void_p(stream), int(iters),
+                                 C.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().sg_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def freqs(nfft: int, fs: float):
+    import numpy as np
+    out = np.empty(nfft // 2 + 1, np.float64)
+    check(lib().sg_freqs(int(nfft), float(fs), out.ctypes.data_as(C.POINTER(_d))))
+    return out
+
+
+def times(n_samples: int, nperseg: int, hop: int, fs: float):
+    import numpy as np
+    n = 0 if n_samples < nperseg else (n_samples - nperseg) // hop + 1
+    out = np.empty(n, np.float64)
+    if n:
+        check(lib().sg_times(int(n_samples), int(nperseg), int(hop), float(fs), out.ctypes.data_as(C.POINTER(_d))))
+    return out

@@ -1,0 +1,243 @@
+"""GPU parity tests proper: HIP path (through the C ABI / ctypes) vs the CPU oracle and the
+committed golden vectors.  Run on the MI355X box with ``pytest -m gpu``.
+
+Tolerance (fp32 path, BASELINE.md §2 / SURVEY H2), written out in conftest.assert_spec_close:
+  per frame |gpu - ref| <= 1e-4 * max_k ref[k];  normwise ||gpu-ref||/||ref|| <= 1e-5;
+  per-bin rtol 1e-4 for bins >= 1e-3 * frame max.
+f64 path: 1e-11 relative to the frame max.  Frame indexing, f and t: bit-exact.
+"""
+import json
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import assert_spec_close, cfg1_signal, cfg2_clips, eeg_like, load_golden, sweep_clip
+from oracle import stft_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sp():
+    import spectro
+    from spectro import _capi
+    _capi.ensure_device()
+    return spectro
+
+
+def _is_pow2(n):
+    return n > 0 and (n & (n - 1)) == 0
+
+
+def _check(got, ref, dtype):
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert got.dtype == ref.dtype, (got.dtype, ref.dtype)
+    if dtype == np.float64:
+        g, r = np.asarray(got), np.asarray(ref)
+        if r.size:
+            fmax = np.abs(r).max(axis=-2, keepdims=True) if r.ndim > 1 else np.abs(r).max()
+            assert np.all(np.abs(g - r) <= 1e-11 * fmax + 1e-300), float(np.max(np.abs(g - r) / (fmax + 1e-300)))
+    else:
+        assert_spec_close(got, ref, time_axis=-1)
+
+
+# ---------------------------------------------------------------- headline kernel (r8x3)
+@pytest.mark.parametrize("tag", ["ext", "ref"])
+def test_cfg2_golden_and_oracle(sp, tag):
+    g = load_golden("g3_cfg2_sampled.npz")
+    clips = cfg2_clips(2)
+    kw = dict(window="hann", noverlap=768) if tag == "ext" else {}
+    f, t, s = sp.spectrogram(clips, fs=48000.0, nperseg=1024, scaling="density", mode="psd", **kw)
+    np.testing.assert_array_equal(f, g[f"{tag}__f"])          # bit-exact
+    np.testing.assert_array_equal(t, g[f"{tag}__t"])          # bit-exact
+    assert s.dtype == np.float32 and s.shape == (2, 513, 1872 if tag == "ext" else 535)
+    idx = g[f"{tag}__frame_idx"]
+    assert_spec_close(np.moveaxis(s[:, :, idx], -1, 1), g[f"{tag}__frames"], time_axis=1)
+    assert np.allclose(s.astype(np.float64).sum(axis=1), g[f"{tag}__frame_sums"], rtol=2e-5)
+    # every frame against the oracle
+    _, _, so = orc.spectrogram(clips, fs=48000.0, nperseg=1024, **kw)
+    assert_spec_close(s, so, time_axis=-1)
+
+
+def test_r8x3_is_the_kernel_and_matches_stockham(sp):
+    from spectro import _capi
+    from spectro.signal import plan_for
+    from spectro.windows import get_window
+    rng = np.random.default_rng(11)
+    x = (rng.standard_normal((3, 30000)) * 0.3 + 0.7).astype(np.float32)
+    win = get_window("hann", 1024)
+    plan = plan_for(win, 1024, 1024, 256, 1, 48000.0, 0, 0, _capi.F32)
+    assert plan.kernel == "r8x3"
+    nfr, nb = plan.n_frames(30000), 513
+    d_in, d_a, d_b = _capi.DeviceBuffer(x.nbytes), _capi.DeviceBuffer(3 * nfr * nb * 4), _capi.DeviceBuffer(3 * nfr * nb * 4)
+    d_in.upload(x)
+    plan.stft(d_in.ptr, 30000, 30000, 3, d_a.ptr, nfr * nb)
+    plan.force_kernel("stockham")
+    try:
+        assert plan.kernel == "stockham"
+        plan.stft(d_in.ptr, 30000, 30000, 3, d_b.ptr, nfr * nb)
+    finally:
+        plan.force_kernel("r8x3")
+    a, b = np.empty((3, nfr, nb), np.float32), np.empty((3, nfr, nb), np.float32)
+    d_a.download(a)
+    d_b.download(b)
+    _capi.stream_sync()
+    assert_spec_close(a, b, time_axis=1)
+    _, _, so = orc.spectrogram(x, fs=48000.0, nperseg=1024, window="hann", noverlap=768)
+    assert_spec_close(np.moveaxis(a, 1, 2), so, time_axis=-1)
+
+
+@pytest.mark.parametrize("hop,detrend,mode", [(255, "constant", "psd"), (1, "constant", "psd"), (1024, False, "psd"),
+                                              (896, "constant", "magnitude"), (333, False, "magnitude")])
+def test_r8x3_variants(sp, hop, detrend, mode):
+    rng = np.random.default_rng(hop)
+    n = 1024 + hop * 37 + 5
+    x = (rng.standard_normal((2, n)) + 2.0).astype(np.float32)
+    kw = dict(fs=1000.0, nperseg=1024, window=("tukey", 0.25), noverlap=1024 - hop, detrend=detrend, mode=mode)
+    f, t, s = sp.spectrogram(x, **kw)
+    fo, to, so = orc.spectrogram(x, **kw)
+    np.testing.assert_array_equal(f, fo)
+    np.testing.assert_array_equal(t, to)
+    assert_spec_close(s, so, time_axis=-1)
+
+
+def test_r8x3_int16_input(sp):
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal((2, 20000)) * 4000).astype(np.int16)
+    f, t, s = sp.spectrogram(x, fs=8000.0, nperseg=1024)
+    _, _, so = orc.spectrogram(x, fs=8000.0, nperseg=1024)
+    assert s.dtype == so.dtype == np.float32
+    assert_spec_close(s, so, time_axis=-1)
+
+
+def test_full_size_properties(sp):
+    """BASELINE cfg2 at full size (64 x 480000): size-independent properties.
+
+    (1) Parseval per frame: sum_k Sxx[k] * fs * sum(w^2) / n  ==  sum_n ((x-mean)*w)^2   (one-sided doubling
+        makes the PSD bins sum to the full two-sided energy);
+    (2) linearity in amplitude: Sxx(a*x) == a^2 * Sxx(x);
+    (3) clip independence: clip c of the batch equals the same clip run alone.
+    """
+    from spectro.windows import get_window
+    x = np.random.default_rng(1234).standard_normal((64, 480000)).astype(np.float32) * np.float32(0.1)
+    f, t, s = sp.spectrogram(x, fs=48000.0, nperseg=1024, window="hann", noverlap=768)
+    assert s.shape == (64, 513, 1872)
+    w = get_window("hann", 1024)
+    for c, fr in [(0, 0), (17, 911), (63, 1871)]:
+        seg = x[c, fr * 256: fr * 256 + 1024].astype(np.float64)
+        seg = (seg - seg.mean()) * w
+        lhs = s[c, :, fr].astype(np.float64).sum() * 48000.0 * (w * w).sum() / 1024
+        assert abs(lhs - (seg ** 2).sum()) <= 2e-5 * (seg ** 2).sum()
+    _, _, s2 = sp.spectrogram(x[:4] * np.float32(4.0), fs=48000.0, nperseg=1024, window="hann", noverlap=768)
+    assert_spec_close(s2, s[:4] * np.float32(16.0), time_axis=-1)
+    _, _, s1 = sp.spectrogram(x[40], fs=48000.0, nperseg=1024, window="hann", noverlap=768)
+    np.testing.assert_array_equal(s1, s[40])
+
+
+# ---------------------------------------------------------------- general kernel
+G2_KW = {
+    "ref": dict(nperseg=512),
+    "hann256": dict(nperseg=512, window="hann", noverlap=256),
+    "hann256_nodetrend": dict(nperseg=512, window="hann", noverlap=256, detrend=False),
+    "hann256_linear": dict(nperseg=512, window="hann", noverlap=256, detrend="linear"),
+    "hann256_mag": dict(nperseg=512, window="hann", noverlap=256, mode="magnitude"),
+    "hann256_spectrum": dict(nperseg=512, window="hann", noverlap=256, scaling="spectrum"),
+    "hann256_complex": dict(nperseg=512, window="hann", noverlap=256, mode="complex"),
+    "hann256_nfft1024": dict(nperseg=512, window="hann", noverlap=256, nfft=1024),
+}
+
+
+@pytest.mark.parametrize("tag", sorted(G2_KW))
+@pytest.mark.parametrize("dt", ["float64", "float32"])
+def test_cfg1_golden(sp, tag, dt):
+    g = load_golden("g2_cfg1_extended.npz")
+    x = cfg1_signal().astype(dt)
+    f, t, s = sp.spectrogram(x, fs=16000.0, **{"scaling": "density", "mode": "psd", **G2_KW[tag]})
+    key = f"{tag}_{dt}"
+    np.testing.assert_array_equal(f, g[key + "__f"])
+    np.testing.assert_array_equal(t, g[key + "__t"])
+    ref = g[key + "__Sxx"]
+    if tag == "hann256_linear" and dt == "float64":
+        assert s.shape == ref.shape and np.abs(s - ref).max() <= 1e-9 * np.abs(ref).max()
+    else:
+        _check(s, ref, np.dtype(dt))
+
+
+def test_angle_and_phase_modes(sp):
+    x = cfg1_signal()[:6000]
+    for mode in ("angle", "phase"):
+        f, t, s = sp.spectrogram(x, fs=16000.0, nperseg=256, window="hann", noverlap=128, mode=mode)
+        _, _, so = orc.spectrogram(x, fs=16000.0, nperseg=256, window="hann", noverlap=128, mode=mode)
+        _, _, mag = orc.spectrogram(x, fs=16000.0, nperseg=256, window="hann", noverlap=128, mode="magnitude")
+        assert s.shape == so.shape
+        if mode == "angle":
+            d = np.angle(np.exp(1j * (s - so)))
+            strong = mag > 1e-3 * mag.max()
+            assert np.abs(d[strong]).max() < 1e-9
+
+
+def test_sweep_golden(sp):
+    g = load_golden("g4_sweep.npz")
+    x = sweep_clip()
+    for n in (256, 512, 1024, 2048, 4096):
+        for hop in (64, 128, 256):
+            k = f"n{n}_h{hop}"
+            f, t, s = sp.spectrogram(x, fs=48000.0, nperseg=n, window="hann", noverlap=n - hop)
+            assert s.shape[-1] == int(g[k + "__nframes"])
+            np.testing.assert_array_equal([t[0], t[-1]], g[k + "__t_ends"])
+            assert_spec_close(s[:, g[k + "__frame_idx"]].T, g[k + "__frames"], time_axis=0)
+            assert np.allclose(s.astype(np.float64).sum(axis=0), g[k + "__frame_sums"], rtol=2e-5)
+
+
+G5_TAGS = ["short", "exact", "exact_plus", "two", "odd33", "np2_1000", "np2_96", "int16", "zeros", "const",
+           "dc_large", "n8192", "n32", "hop1", "default_nperseg", "batch2d"]
+
+
+@pytest.mark.parametrize("tag", G5_TAGS)
+def test_edges_golden(sp, tag):
+    g = load_golden("g5_edges.npz")
+    kw = json.loads(str(g[tag + "__kw"]))
+    fs = kw.pop("fs")
+    x = g[tag + "__x"]
+    with warnings.catch_warnings(record=True) as wl:
+        warnings.simplefilter("always")
+        f, t, s = sp.spectrogram(x, fs=fs, **kw)
+    assert int(any("nperseg" in str(w.message) for w in wl)) == int(g[tag + "__warned"])
+    np.testing.assert_array_equal(f, g[tag + "__f"])
+    np.testing.assert_array_equal(t, g[tag + "__t"])
+    ref = g[tag + "__Sxx"]
+    assert s.shape == ref.shape and s.dtype == ref.dtype
+    if tag in ("const", "zeros"):
+        assert np.abs(s - ref).max() <= 1e-6 * max(float(np.abs(x).max()) ** 2, 1e-12)
+    elif tag == "dc_large":
+        # mean 100, signal 1e-3: fp32 cancellation noise; bound relative to the *signal* power scale
+        assert np.abs(s - ref).max() <= 5e-3 * np.abs(ref).max()
+    else:
+        _check(s, ref, ref.dtype)
+
+
+def test_axis_argument(sp):
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((700, 3)).astype(np.float32)
+    import scipy.signal as ss
+    f, t, s = sp.spectrogram(x, fs=100.0, nperseg=64, axis=0)
+    fr, tr, sr = ss.spectrogram(x, fs=100.0, nperseg=64, axis=0)
+    assert s.shape == sr.shape
+    assert_spec_close(s, sr, time_axis=-1)
+
+
+def test_argument_errors(sp):
+    x = np.zeros(1000, np.float32)
+    with pytest.raises(ValueError):
+        sp.spectrogram(x, nperseg=64, noverlap=64)
+    with pytest.raises(ValueError):
+        sp.spectrogram(x, nperseg=64, nfft=32)
+    with pytest.raises(ValueError):
+        sp.spectrogram(x, nperseg=64, mode="nope")
+    with pytest.raises(ValueError):
+        sp.spectrogram(x, nperseg=64, scaling="nope")
+    with pytest.raises(ValueError):
+        sp.spectrogram(x, window=np.ones(2000))
+    with pytest.raises(NotImplementedError):
+        sp.spectrogram(x.astype(np.complex64), nperseg=64)
