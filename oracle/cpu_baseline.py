@@ -1,0 +1,84 @@
+"""CPU baseline leg of bench.py -- TEST/BENCH INFRASTRUCTURE, never imported by the product.
+
+Times what the reference itself runs on this path: ``scipy.signal.spectrogram`` (the callable
+imported at PlotEngine.py:8 and invoked at PlotEngine.py:113/232) with the benchmark's argument
+set, on the host cores of the box bench.py runs on.  If scipy is absent there, the numpy
+restatement (oracle/stft_oracle.py) is timed instead and the result is labelled "port".
+"""
+from __future__ import annotations
+
+import os
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+
+def _callable():
+    try:
+        import scipy
+        from scipy.signal import spectrogram
+        return spectrogram, "reference", f"scipy {scipy.__version__}"
+    except Exception:                                   # pragma: no cover - scipy is in the image
+        from oracle.stft_oracle import spectrogram
+        return spectrogram, "port", f"numpy {np.__version__} restatement"
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def time_cpu_baseline(clips: np.ndarray, fs: float, nperseg: int, hop: int, window="hann",
+                      budget_s: float = 20.0, threads: int | None = None):
+    """Best-of-N wall time over ``clips`` ([n_clips, N] f32), single thread and a clip-parallel pool.
+
+    Returns a dict ready to be dropped into bench.py's ``cpu_baseline`` object.
+    """
+    fn, kind, lib = _callable()
+    kw = dict(fs=fs, nperseg=nperseg, window=window, noverlap=nperseg - hop, scaling="density", mode="psd")
+    n_frames = ((clips.shape[1] - nperseg) // hop + 1) * clips.shape[0]
+    threads = threads or min(os.cpu_count() or 1, clips.shape[0])
+
+    def one(c):
+        return fn(clips[c], **kw)[2].shape
+
+    def run_serial():
+        t0 = time.perf_counter()
+        for c in range(clips.shape[0]):
+            one(c)
+        return time.perf_counter() - t0
+
+    def run_pool(pool):
+        t0 = time.perf_counter()
+        list(pool.map(one, range(clips.shape[0])))
+        return time.perf_counter() - t0
+
+    one(0)                                              # warm-up (plan caches, page faults)
+    t_start = time.perf_counter()
+    best1 = run_serial()
+    reps1 = 1
+    while time.perf_counter() - t_start < budget_s * 0.5 and reps1 < 5:
+        best1 = min(best1, run_serial())
+        reps1 += 1
+    with ThreadPoolExecutor(threads) as pool:
+        run_pool(pool)
+        bestn = run_pool(pool)
+        repsn = 1
+        while time.perf_counter() - t_start < budget_s and repsn < 5:
+            bestn = min(bestn, run_pool(pool))
+            repsn += 1
+    return {
+        "value": n_frames / bestn, "unit": "frames/s", "cores": threads, "kind": kind,
+        "single_thread_value": n_frames / best1,
+        "sample": (f"{lib} spectrogram(fs={fs:g}, nperseg={nperseg}, window='{window}', noverlap={nperseg - hop}, "
+                   f"density psd) on {clips.shape[0]} clips x {clips.shape[1]} f32 samples = {n_frames} frames; "
+                   f"best of {repsn} (pool of {threads} threads over clips) / best of {reps1} (1 thread); "
+                   f"host: {cpu_model()}, {os.cpu_count()} logical CPUs"),
+    }

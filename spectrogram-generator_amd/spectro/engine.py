@@ -1,0 +1,255 @@
+"""Device-resident spectrogram objects and the epilogues the reference applies to them.
+
+``DeviceSpectrogram`` keeps the frame-major spectrum of one ``stft()`` call in HBM and offers
+the reference's post-processing (PlotEngine.py:114-131, :238-241, :686-719) as device kernels:
+
+    mask + store      -> band_slice()        (A8)
+    normalise / dB    -> image()             (A9, A10)
+    band log-power    -> features()          (A11; fused variant: band_features())
+    power summaries   -> total_power(), band_totals()   (A12, A13)
+
+Everything numeric runs through libspectro.so; numpy is used for shapes and host copies only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import warnings
+
+import numpy as np
+
+from . import _capi
+from .signal import compute_dtype, plan_for, resolve_segments
+
+__all__ = ["DeviceSpectrogram", "stft", "band_features", "bin_range"]
+
+
+def bin_range(f: np.ndarray, fmin: float, fmax: float):
+    """Index range [k_lo, k_hi] of ``(f >= fmin) & (f <= fmax)`` (inclusive both ends,
+    PlotEngine.py:114/:238); ``f`` is ascending so the mask is one contiguous run.
+    Returns ``(k_lo, k_hi)`` with ``k_lo > k_hi`` when the mask is empty."""
+    k_lo = int(np.searchsorted(f, fmin, side="left"))
+    k_hi = int(np.searchsorted(f, fmax, side="right")) - 1
+    return k_lo, k_hi
+
+
+def _np_dtype(code):
+    return np.float32 if code == _capi.F32 else np.float64
+
+
+class DeviceSpectrogram:
+    """Frame-major PSD ``[n_clips][n_frames][n_bins]`` resident in HBM plus its f / t vectors."""
+
+    def __init__(self, buf, dtype_code, n_clips, n_frames, n_bins, f, t, fs, plan=None, outer=()):
+        self.buf, self.dtype_code = buf, dtype_code
+        self.n_clips, self.n_frames, self.n_bins = n_clips, n_frames, n_bins
+        self.f, self.t, self.fs, self.plan, self.outer = f, t, fs, plan, outer
+        self._scratch = _capi.DeviceBuffer(64)
+
+    @property
+    def dtype(self):
+        return _np_dtype(self.dtype_code)
+
+    @property
+    def rows(self):
+        return self.n_clips * self.n_frames
+
+    def free(self):
+        for b in (self.buf, self._scratch):
+            if b is not None:
+                b.free()
+        self.buf = None
+
+    # ---- host copies -----------------------------------------------------
+    def to_host(self):
+        """Full spectrum as scipy lays it out: ``[..., n_bins, n_frames]`` (view of frame-major memory)."""
+        out = np.empty((self.n_clips, self.n_frames, self.n_bins), self.dtype)
+        if out.size:
+            self.buf.download(out)
+            _capi.stream_sync()
+        return np.moveaxis(out.reshape(*self.outer, self.n_frames, self.n_bins), -1, -2)
+
+    def band_slice(self, k_lo, k_hi):
+        """A8: ``Sxx[mask, :]`` for one clip batch -> host array ``[..., n_mask, n_frames]``."""
+        width = max(k_hi - k_lo + 1, 0)
+        out = np.empty((self.n_clips, self.n_frames, width), self.dtype)
+        if out.size:
+            d = _capi.DeviceBuffer(out.nbytes)
+            try:
+                _capi.check(_capi.lib().sg_slice_bins(C.c_void_p(self.buf.ptr), self.dtype_code, self.rows, self.n_bins,
+                                                      k_lo, k_hi, C.c_void_p(d.ptr), None))
+                d.download(out)
+                _capi.stream_sync()
+            finally:
+                d.free()
+        return np.moveaxis(out.reshape(*self.outer, self.n_frames, width), -1, -2)
+
+    # ---- A9 / A10 ----------------------------------------------------------
+    def image(self, k_lo, k_hi, log_scale, global_max=None):
+        """Normalised display image over bins [k_lo, k_hi] (PlotEngine.py:126-131) -> ``[n_mask, n_frames]``.
+
+        ``base = max(S)`` over the band unless ``global_max > 0``; with ``log_scale`` the dB image is
+        min-max rescaled to [0, 1] (zeros when the dB range is <= 1e-6)."""
+        width = k_hi - k_lo + 1
+        out = np.empty((self.n_clips, self.n_frames, width), self.dtype)
+        if out.size:
+            d = _capi.DeviceBuffer(out.nbytes)
+            try:
+                gm = 0.0 if (global_max is None or global_max <= 0) else float(global_max)
+                _capi.check(_capi.lib().sg_normalise_image(
+                    C.c_void_p(self.buf.ptr), self.dtype_code, self.rows, self.n_bins, k_lo, k_hi, int(bool(log_scale)),
+                    gm, C.c_void_p(d.ptr), C.c_void_p(self._scratch.ptr), None))
+                d.download(out)
+                _capi.stream_sync()
+            finally:
+                d.free()
+        return np.moveaxis(out.reshape(*self.outer, self.n_frames, width), -1, -2)
+
+    def minmax(self, k_lo, k_hi):
+        mm = np.empty(2, self.dtype)
+        _capi.check(_capi.lib().sg_minmax(C.c_void_p(self.buf.ptr), self.dtype_code, self.rows, self.n_bins, k_lo, k_hi,
+                                          C.c_void_p(self._scratch.ptr), None))
+        self._scratch.download(mm)
+        _capi.stream_sync()
+        return mm[0], mm[1]
+
+    # ---- A11 ---------------------------------------------------------------
+    def features(self, k_lo, k_hi):
+        """``column_stack[log10(sum_band + 1e-20), diff(prepend first)]`` -> ``[n_frames, 2]`` (first clip)."""
+        band = _capi.DeviceBuffer(max(self.rows, 1) * np.dtype(self.dtype).itemsize)
+        try:
+            _capi.check(_capi.lib().sg_band_sum(C.c_void_p(self.buf.ptr), self.dtype_code, self.rows, self.n_bins, k_lo, k_hi,
+                                                C.c_void_p(band.ptr), None))
+            return _features_from_band(band, self.dtype_code, self.n_clips, self.n_frames)
+        finally:
+            band.free()
+
+    # ---- A12 / A13 ---------------------------------------------------------
+    def band_totals(self, ranges):
+        """``sum over frames of sum_{k in [lo, hi)} max(0, S[f][k])`` per half-open bin range (double)."""
+        ranges = list(ranges)
+        out = np.zeros(len(ranges), np.float64)
+        for i in range(0, len(ranges), 16):
+            part = ranges[i:i + 16]
+            lo = (C.c_int * len(part))(*[int(r[0]) for r in part])
+            hi = (C.c_int * len(part))(*[int(r[1]) for r in part])
+            d = _capi.DeviceBuffer(8 * len(part))
+            try:
+                _capi.check(_capi.lib().sg_band_totals(C.c_void_p(self.buf.ptr), self.dtype_code, self.rows, self.n_bins,
+                                                       len(part), lo, hi, C.c_void_p(d.ptr), None))
+                d.download(out[i:i + len(part)])
+                _capi.stream_sync()
+            finally:
+                d.free()
+        return out
+
+
+def _features_from_band(band, dtype_code, n_clips, n_frames):
+    dt = _np_dtype(dtype_code)
+    feats = np.empty((n_clips, n_frames, 2), dt)
+    if feats.size:
+        d = _capi.DeviceBuffer(feats.nbytes)
+        try:
+            isz = np.dtype(dt).itemsize
+            for c in range(n_clips):          # the diff must not cross clip boundaries
+                _capi.check(_capi.lib().sg_band_features(C.c_void_p(band.ptr + c * n_frames * isz), dtype_code, n_frames,
+                                                         C.c_void_p(d.ptr + c * n_frames * 2 * isz), None))
+            d.download(feats)
+            _capi.stream_sync()
+        finally:
+            d.free()
+    return feats
+
+
+def _prepare(x, fs, window, nperseg, noverlap, nfft, detrend, scaling, mode):
+    x = np.asarray(x)
+    if np.iscomplexobj(x):
+        raise NotImplementedError("complex input is outside the device path")
+    win, nperseg = resolve_segments(window, nperseg, input_length=x.shape[-1])
+    if noverlap is None:
+        noverlap = nperseg // 8
+    if nfft is None:
+        nfft = nperseg
+    elif nfft < nperseg:
+        raise ValueError("nfft must be greater than or equal to nperseg.")
+    if noverlap >= nperseg:
+        raise ValueError("noverlap must be less than nperseg.")
+    if detrend not in _capi.DETREND:
+        raise ValueError("Trend type must be 'linear' or 'constant'.")
+    hop = nperseg - int(noverlap)
+    cdt = compute_dtype(x.dtype)
+    code = _capi.F32 if cdt == np.float32 else _capi.F64
+    plan = plan_for(win, nperseg, int(nfft), hop, _capi.DETREND[detrend], fs, _capi.SCALING[scaling],
+                    _capi.MODE[mode], code)
+    outer = x.shape[:-1]
+    n_clips = int(np.prod(outer)) if outer else 1
+    use_i16 = x.dtype == np.int16 and plan.kernel != "bluestein"
+    xh = np.ascontiguousarray(x.reshape(n_clips, x.shape[-1]), dtype=np.int16 if use_i16 else cdt)
+    return plan, xh, use_i16, outer, n_clips, code, nperseg, hop, int(nfft)
+
+
+def stft(x, fs=1.0, window=("tukey", .25), nperseg=None, noverlap=None, nfft=None, detrend="constant",
+         scaling="density", mode="psd") -> DeviceSpectrogram:
+    """Like ``spectro.spectrogram`` (last axis) but the spectrum stays on the device."""
+    if mode not in ("psd", "magnitude"):
+        raise ValueError("stft() keeps real spectra on the device: mode must be 'psd' or 'magnitude'")
+    plan, xh, use_i16, outer, n_clips, code, nperseg, hop, nfft = _prepare(x, fs, window, nperseg, noverlap, nfft, detrend, scaling, mode)
+    n_samples = xh.shape[1]
+    n_frames, n_bins = plan.n_frames(n_samples), plan.n_bins
+    isz = 4 if code == _capi.F32 else 8
+    d_in = _capi.DeviceBuffer(max(xh.nbytes, 8))
+    d_out = _capi.DeviceBuffer(max(n_clips * n_frames * n_bins * isz, 8))
+    try:
+        d_in.upload(xh)
+        plan.stft(d_in.ptr, n_samples, n_samples, n_clips, d_out.ptr, n_frames * n_bins, int16=use_i16)
+        _capi.stream_sync()
+    except Exception:
+        d_out.free()
+        raise
+    finally:
+        d_in.free()
+    return DeviceSpectrogram(d_out, code, n_clips, n_frames, n_bins, _capi.freqs(nfft, fs),
+                             _capi.times(n_samples, nperseg, hop, fs), fs, plan, outer)
+
+
+def band_features(x, fs, nperseg, fmin, fmax, window=("tukey", .25), noverlap=None, detrend="constant"):
+    """A11 fused: the spectrogram never reaches HBM -- per frame only the band sum is written (8 B/frame
+    instead of 2052 B/frame at nfft = 1024), then log10 / diff.  Returns ``(t, feats[n_frames, 2])`` for a
+    1-D signal, ``(None, None)`` when there are no frames (PlotEngine.py:236)."""
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")           # the reference's second call re-triggers the nperseg warning; stay quiet here
+        plan, xh, use_i16, outer, n_clips, code, nperseg, hop, nfft = _prepare(x, fs, window, nperseg, noverlap, None, detrend, "density", "psd")
+    n_samples = xh.shape[1]
+    n_frames = plan.n_frames(n_samples)
+    if xh.size == 0 or n_frames == 0:
+        return None, None
+    f = _capi.freqs(nfft, fs)
+    t = _capi.times(n_samples, nperseg, hop, fs)
+    k_lo, k_hi = bin_range(f, fmin, fmax)
+    dt = _np_dtype(code)
+    if k_lo > k_hi:      # empty mask: np.sum over no rows = 0 -> log10(1e-20) = -20, diff 0 (PlotEngine.py:239-241)
+        feats = np.zeros((n_clips, n_frames, 2), dt)
+        feats[..., 0] = np.log10(dt(0) + 1e-20)
+        return t, feats.reshape(*outer, n_frames, 2)
+    if use_i16:
+        xh = xh.astype(dt)
+    isz = np.dtype(dt).itemsize
+    d_in = _capi.DeviceBuffer(xh.nbytes)
+    band = _capi.DeviceBuffer(n_clips * n_frames * isz)
+    try:
+        d_in.upload(xh)
+        if plan.kernel == "bluestein":
+            spec = _capi.DeviceBuffer(n_clips * n_frames * plan.n_bins * isz)
+            try:
+                plan.stft(d_in.ptr, n_samples, n_samples, n_clips, spec.ptr, n_frames * plan.n_bins)
+                _capi.check(_capi.lib().sg_band_sum(C.c_void_p(spec.ptr), code, n_clips * n_frames, plan.n_bins, k_lo, k_hi,
+                                                    C.c_void_p(band.ptr), None))
+                _capi.stream_sync()
+            finally:
+                spec.free()
+        else:
+            plan.band_power(d_in.ptr, n_samples, n_samples, n_clips, k_lo, k_hi, band.ptr, n_frames)
+        feats = _features_from_band(band, code, n_clips, n_frames)
+    finally:
+        d_in.free()
+        band.free()
+    return t, feats.reshape(*outer, n_frames, 2)

@@ -1,0 +1,141 @@
+"""GPU parity of the post-processing rows A8-A13 and of the PlotEngine drop-in, against the goldens that
+were produced by the reference's own PlotEngine methods (g1_reference_engine.npz) and against the oracle."""
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import assert_spec_close, cfg1_signal, eeg_like, load_golden
+from oracle import stft_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+SIGNALS = {
+    "cfg1_lin": lambda: cfg1_signal(), "cfg1_log": lambda: cfg1_signal(),
+    "cfg1_band_log": lambda: cfg1_signal(), "cfg1_gmax": lambda: cfg1_signal(),
+    "cfg1_f32": lambda: cfg1_signal().astype(np.float32),
+    "eeg_default": eeg_like, "eeg_lin_256": eeg_like,
+    "short_clamp": lambda: cfg1_signal()[:300],
+    "zeros": lambda: np.zeros(4096), "const": lambda: np.full(4096, 2.5),
+    "empty_mask": lambda: cfg1_signal(),
+    "eeg_np2_1000": eeg_like,
+}
+
+
+def _settings(g, tag):
+    fs, nper, fmin, fmax, log, gmax = g[f"{tag}__args"]
+    return fs, {"nperseg": int(nper), "fmin": fmin, "fmax": fmax, "log_scale": bool(log), "mode_raw": "Spectrogram",
+                "mode_proc": "None", "draw_raw": False, "draw_proc": False}, (None if gmax < 0 else gmax)
+
+
+@pytest.mark.parametrize("tag", sorted(SIGNALS))
+def test_plotengine_matches_reference_engine(tag):
+    from PlotEngine import PlotEngine
+    g = load_golden("g1_reference_engine.npz")
+    fs, settings, gmax = _settings(g, tag)
+    x = SIGNALS[tag]()
+    eng = PlotEngine()
+    captured = {}
+    real = eng.ax_spec.pcolormesh
+
+    def spy(t, f, img, **kw):
+        captured["img"] = np.array(img, copy=True)
+        return real(t, f, img, **kw)
+    eng.ax_spec.pcolormesh = spy
+    with warnings.catch_warnings(record=True) as wl:
+        warnings.simplefilter("always")
+        if gmax is None:
+            eng.plot_extra(x, None, fs, settings)
+        else:
+            eng.last_fs, eng.last_settings, eng.spec_data_source = fs, settings, x
+            eng._plot_spectrogram(x, fs, settings, gmax)
+        tf, feats = eng._calculate_features(x, fs, settings)
+    assert (sum("nperseg" in str(w.message) for w in wl) > 0) == (int(g[f"{tag}__n_warnings"]) > 0)
+    np.testing.assert_array_equal(eng.last_f, g[f"{tag}__last_f"])            # bit-exact
+    np.testing.assert_array_equal(eng.last_t, g[f"{tag}__last_t"])            # bit-exact
+    ref = g[f"{tag}__last_Sxx"]
+    assert eng.last_Sxx.shape == ref.shape and eng.last_Sxx.dtype == ref.dtype
+    f64 = ref.dtype == np.float64
+    if ref.size and tag not in ("zeros", "const"):
+        if f64:
+            assert np.abs(eng.last_Sxx - ref).max() <= 1e-11 * np.abs(ref).max()
+        else:
+            assert_spec_close(eng.last_Sxx, ref, time_axis=-1)
+    elif ref.size:
+        assert np.abs(eng.last_Sxx - ref).max() <= 1e-12
+    ref_img = g[f"{tag}__image"]
+    if ref_img.size == 0:
+        assert "img" not in captured
+    else:
+        assert captured["img"].shape == ref_img.shape
+        assert np.abs(captured["img"] - ref_img).max() <= (1e-9 if f64 else 2e-4)
+    ref_feats = g[f"{tag}__feats"]
+    if ref_feats.shape[0] == 0:
+        assert feats is None
+    else:
+        np.testing.assert_array_equal(tf, g[f"{tag}__feat_t"])
+        assert feats.shape == ref_feats.shape and feats.dtype == ref_feats.dtype
+        if tag in ("zeros", "const"):
+            assert np.all(feats[:, 0] <= -19.0) or np.allclose(feats, ref_feats, atol=0.5)
+        else:
+            assert np.allclose(feats, ref_feats, rtol=0, atol=1e-9 if f64 else 2e-5)
+    ap = eng.calculate_absolute_power()
+    assert np.isclose(ap, g[f"{tag}__abs_power"], rtol=1e-10 if f64 else 1e-5, atol=1e-12)
+    bp = eng.calculate_band_powers()
+    assert list(bp.keys()) == [str(s) for s in g[f"{tag}__band_names"]]
+    assert np.allclose([float(v) for v in bp.values()], g[f"{tag}__band_values"], rtol=1e-9 if f64 else 1e-5, atol=1e-12)
+
+
+def test_plot_sweeps_combine_and_export_surface():
+    """plot_sweeps with combine=True: segment_map, last_raw_t, combined_* and the spectrogram of the concatenation."""
+    from PlotEngine import PlotEngine
+    rng = np.random.default_rng(4)
+    a, b = rng.standard_normal(3000), rng.standard_normal(2000)
+    items = ["itemA", "itemB"]
+    infos = [{"item": items[0], "signal_raw": a, "signal_proc": None, "fs": 500.0},
+             {"item": items[1], "signal_raw": b, "signal_proc": None, "fs": 500.0}]
+    settings = {"combine": True, "draw_raw": True, "draw_proc": False, "mode_raw": "Both", "mode_proc": "None",
+                "nperseg": 256, "fmin": 0.0, "fmax": 100.0, "log_scale": True}
+    eng = PlotEngine()
+    eng.plot_sweeps(infos, settings)
+    assert eng.currently_plotted_items == items
+    assert [m["source_item"] for m in eng.segment_map] == items
+    assert eng.segment_map[0]["end_time_combined"] == 6.0 and eng.segment_map[1]["end_time_combined"] == 10.0
+    joined = np.concatenate([a, b])
+    np.testing.assert_array_equal(eng.combined_raw, joined)
+    np.testing.assert_array_equal(eng.last_raw_t, np.arange(5000) / 500.0)
+    f, t, s = orc.spectrogram(joined, fs=500.0, nperseg=256)
+    lf, lt, ls, img = orc.plot_image(f, t, s, 0.0, 100.0, True)
+    np.testing.assert_array_equal(eng.last_f, lf)
+    np.testing.assert_array_equal(eng.last_t, lt)
+    assert np.abs(eng.last_Sxx - ls).max() <= 1e-11 * ls.max()
+    assert eng.spec_data_source is not None and eng.last_fs == 500.0
+
+
+def test_device_epilogues_vs_oracle_f32_batch():
+    from spectro import engine
+    rng = np.random.default_rng(12)
+    x = (rng.standard_normal((3, 20000)) * 0.2).astype(np.float32)
+    dev = engine.stft(x, fs=8000.0, nperseg=1024)
+    f, t, s = orc.spectrogram(x, fs=8000.0, nperseg=1024)
+    assert_spec_close(dev.to_host(), s, time_axis=-1)
+    k_lo, k_hi = engine.bin_range(f, 100.0, 2500.0)
+    sl = dev.band_slice(k_lo, k_hi)
+    assert_spec_close(sl, s[:, k_lo:k_hi + 1, :], time_axis=-1)
+    lo, hi = dev.minmax(k_lo, k_hi)
+    assert lo == sl.min() and hi == sl.max()
+    # batch-global normalisation (one base for all clips)
+    for log in (False, True):
+        img = dev.image(k_lo, k_hi, log)
+        _, _, _, ref = orc.plot_image(f, t, np.concatenate(list(s), axis=1), 100.0, 2500.0, log)
+        got = np.concatenate(list(img), axis=1)
+        assert np.abs(got - ref).max() <= 2e-4
+    feats = dev.features(k_lo, k_hi)
+    t2, fused = engine.band_features(x, 8000.0, 1024, 100.0, 2500.0)
+    for c in range(3):
+        _, ref = orc.hmm_features(x[c], 8000.0, 1024, 100.0, 2500.0)
+        assert np.allclose(feats[c], ref, atol=2e-5) and np.allclose(fused[c], ref, atol=2e-5)
+    tot = dev.band_totals([(0, 513), (10, 20), (20, 20), (500, 513)])
+    sd = s.astype(np.float64)
+    assert np.allclose(tot, [sd.sum(), sd[:, 10:20].sum(), 0.0, sd[:, 500:513].sum()], rtol=1e-5)
+    dev.free()
