@@ -21,6 +21,10 @@ LIB = os.path.join(LIBDIR, "libspectro.so")
 SOURCES = ["spectro_api.hip", "stft_r8x3.hip", "stft_stockham.hip", "stft_bluestein.hip", "epilogue.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-fno-gpu-rdc",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+# Per-file extras.  stft_r8x3 is VALU-bound: gfx950 issues v_pk_*_f32 at half the rate of the plain ops
+# (tools/ubench/valu_rate.hip: 2.2 ns vs 1.2 ns per wave-instruction per SIMD), so SLP packing only adds
+# register-pair shuffles (v_pk_mov/v_mov) -- keep the scalar forms.
+EXTRA = {"stft_r8x3.hip": ["-fno-slp-vectorize"] + os.environ.get("SG_R8_DEFS", "").split()}
 
 
 def hipcc():
@@ -52,7 +56,7 @@ def build(force=False, verbose=False):
     procs = []
     for s in SOURCES:
         obj = os.path.join(LIBDIR, s.replace(".hip", ".o"))
-        cmd = [hipcc(), *FLAGS, "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", os.path.join(CSRC, s), "-o", obj]
+        cmd = [hipcc(), *FLAGS, *EXTRA.get(s, []), "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", os.path.join(CSRC, s), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

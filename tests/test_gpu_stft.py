@@ -211,8 +211,13 @@ def test_edges_golden(sp, tag):
     if tag in ("const", "zeros"):
         assert np.abs(s - ref).max() <= 1e-6 * max(float(np.abs(x).max()) ** 2, 1e-12)
     elif tag == "dc_large":
-        # mean 100, signal 1e-3: fp32 cancellation noise; bound relative to the *signal* power scale
-        assert np.abs(s - ref).max() <= 5e-3 * np.abs(ref).max()
+        # mean 100, signal 1e-3 in fp32: the samples themselves carry ~1% quantisation and scipy's own fp32 mean is
+        # off by a few ulp, so scipy-f32 is not the truth here.  Judge both against the f64 result on the same samples:
+        # the device path must be at least as close to it as scipy's fp32 path (x2 slack) or within 1e-4 of frame max.
+        _, _, truth = orc.spectrogram(x.astype(np.float64), fs=fs, **kw)
+        err_ref = np.abs(ref.astype(np.float64) - truth).max()
+        err_gpu = np.abs(s.astype(np.float64) - truth).max()
+        assert err_gpu <= max(2.0 * err_ref, 1e-4 * truth.max()), (err_gpu, err_ref)
     else:
         _check(s, ref, ref.dtype)
 
