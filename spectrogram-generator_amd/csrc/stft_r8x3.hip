@@ -49,23 +49,27 @@ __device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.
 
 // In-register 8-point DFT, forward sign, natural order in and out:
 // a[r] <- sum_k a[k] * exp(-2*pi*i*k*r/8).
+// The two 1/sqrt(2) rotations (w8, w8^3) are kept unscaled and the factor is applied inside the last
+// butterfly stage as an FMA (a[1] = c4 + h*c5 ...): 4 multiplies fewer per butterfly.
 __device__ __forceinline__ void radix8(float2 (&a)[8]) {
     constexpr float h = 0.70710678118654752440f;
     const float2 b0 = cadd(a[0], a[4]), b4 = csub(a[0], a[4]);
     const float2 b1 = cadd(a[1], a[5]), b5 = csub(a[1], a[5]);
     const float2 b2 = cadd(a[2], a[6]), b6 = csub(a[2], a[6]);
     const float2 b3 = cadd(a[3], a[7]), b7 = csub(a[3], a[7]);
-    const float2 t5 = make_float2((b5.x + b5.y) * h, (b5.y - b5.x) * h);     // * w8
-    const float2 t6 = mul_mi(b6);                                            // * w8^2
-    const float2 t7 = make_float2((b7.y - b7.x) * h, -(b7.x + b7.y) * h);    // * w8^3
+    const float2 t5 = make_float2(b5.x + b5.y, b5.y - b5.x);       // b5 * w8   * sqrt(2)
+    const float2 t6 = mul_mi(b6);                                  // b6 * w8^2
+    const float2 t7 = make_float2(b7.y - b7.x, -(b7.x + b7.y));    // b7 * w8^3 * sqrt(2)
     const float2 c0 = cadd(b0, b2), c2 = csub(b0, b2);
     const float2 c1 = cadd(b1, b3), c3 = mul_mi(csub(b1, b3));
     const float2 c4 = cadd(b4, t6), c6 = csub(b4, t6);
-    const float2 c5 = cadd(t5, t7), c7 = mul_mi(csub(t5, t7));
+    const float2 c5 = cadd(t5, t7), c7 = mul_mi(csub(t5, t7));     // both still carry sqrt(2)
     a[0] = cadd(c0, c1); a[4] = csub(c0, c1);
     a[2] = cadd(c2, c3); a[6] = csub(c2, c3);
-    a[1] = cadd(c4, c5); a[5] = csub(c4, c5);
-    a[3] = cadd(c6, c7); a[7] = csub(c6, c7);
+    a[1] = make_float2(fmaf(h, c5.x, c4.x), fmaf(h, c5.y, c4.y));
+    a[5] = make_float2(fmaf(-h, c5.x, c4.x), fmaf(-h, c5.y, c4.y));
+    a[3] = make_float2(fmaf(h, c7.x, c6.x), fmaf(h, c7.y, c6.y));
+    a[7] = make_float2(fmaf(-h, c7.x, c6.x), fmaf(-h, c7.y, c6.y));
 }
 
 template <int CTRL>
@@ -201,7 +205,6 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
     float2* const x2w = buf + j0 * kS2 + hi;        // + 8*s
     float2* const x2r = buf + lane;                 // + j0*kS2
     float2* const x3w = buf + lane;                 // + 64*t
-    const float2* const x3a = buf + lane;           // + 64*m
     const float2* const x3b = buf + (kM - lane);    // - 64*m
 
     const float q_in = MODE == 0 ? p.scale * 0.5f : p.scale * 0.25f;     // interior bins (psd: doubled)
@@ -275,8 +278,10 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
 
             // ---- pass 3: lane = r + 8s, DFT over j0 -> Z[lane + 64t]
             radix8(a);
+            // Split pass pairs k = lane + 64m (m = 0..3, still in registers a[0..3]) with 512-k = Z[(64-lane) + 64(7-m)],
+            // which sits in registers a[4..7] of lane 64-lane: only the upper half crosses lanes (4 LDS writes, not 8).
 #pragma unroll
-            for (int t = 0; t < 8; ++t) lds_put(x3w + 64 * t, a[t]);
+            for (int t = 4; t < 8; ++t) lds_put(x3w + 64 * t, a[t]);
             if (lane == 0) lds_put(buf + kM, a[0]);         // Z[512] := Z[0] closes the k <-> 512-k pairing
             wave_lds_fence();
 
@@ -284,13 +289,14 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
             float band = 0.f;
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                const float2 A = lds_get(x3a + 64 * m);
+                const float2 A = a[m];
                 const float2 B = lds_get(x3b - 64 * m);             // Z[512-k]; conj applied below
                 const float2 cs = SG_TW(t3, m);                     // cos, sin of 2*pi*k/1024
                 const float2 S = make_float2(A.x + B.x, A.y - B.y); // A + conj(B)
                 const float2 D = make_float2(A.x - B.x, A.y + B.y); // A - conj(B)
                 const float2 T = make_float2(fmaf(cs.y, D.x, -cs.x * D.y), fmaf(cs.x, D.x, cs.y * D.y));   // i*W^k*D
                 const float2 Xk = csub(S, T), Xm = cadd(S, T);      // 2*X[k], 2*conj(X[512-k])
+                // (|S|^2 + |D|^2 -+ 2Re(S conj T) would save two ops but cancels catastrophically for weak bins)
                 const float q = m == 0 ? q0 : q_in;
                 float pk = fmaf(Xk.x, Xk.x, Xk.y * Xk.y) * q;
                 float pm = fmaf(Xm.x, Xm.x, Xm.y * Xm.y) * q;
@@ -300,21 +306,21 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
                     band += (k >= p.k_lo && k <= p.k_hi) ? pk : 0.f;
                     band += (kM - k >= p.k_lo && kM - k <= p.k_hi) ? pm : 0.f;
                 } else {
-                    __builtin_nontemporal_store(pk, orow + k);
-                    __builtin_nontemporal_store(pm, orow + (kM - k));
+                    orow[k] = pk;
+                    orow[kM - k] = pm;
                 }
             }
-            {   // k = 256 pairs with itself: X[256] = conj(Z[256])
-                const float2 Zq = lds_get(buf + 256);
-                float pq = fmaf(Zq.x, Zq.x, Zq.y * Zq.y) * (q_in * 4.0f);
+            {   // k = 256 pairs with itself: X[256] = conj(Z[256]); Z[256] is lane 0's a[4]
+                const float zx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a[4].x), 0));
+                const float zy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a[4].y), 0));
+                float pq = fmaf(zx, zx, zy * zy) * (q_in * 4.0f);
                 if (MODE == 1) pq = sqrtf(pq);
                 if (BAND) {
                     band += (lane == 0 && 256 >= p.k_lo && 256 <= p.k_hi) ? pq : 0.f;
                 } else {
                     // every lane holds the same pq: a wave-uniform store keeps the loop branch-free, so the
                     // compiler's s_waitcnt for the prefetched loads stays exact (vmcnt = stores issued since)
-                    // instead of draining the oldest store of this frame
-                    __builtin_nontemporal_store(pq, orow + 256);
+                    orow[256] = pq;
                 }
             }
             if (BAND) {
