@@ -74,6 +74,7 @@ int sg_host_alloc(void** host_ptr, size_t bytes); /* pinned */
 int sg_host_free(void* host_ptr);
 int sg_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream);
 int sg_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);
+int sg_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes, void* stream); /* ranges may not overlap */
 int sg_memset(void* dst_dev, int value, size_t bytes, void* stream);
 int sg_stream_create(void** stream);
 int sg_stream_destroy(void* stream);
@@ -161,6 +162,24 @@ int sg_band_totals(const void* spec_dev, int dtype, int64_t n_frames, int n_bins
 /* Copy bins [k_lo,k_hi] of every frame into dst_dev[n_frames][k_hi-k_lo+1] (A8 mask + store). */
 int sg_slice_bins(const void* spec_dev, int dtype, int64_t n_frames, int n_bins, int k_lo, int k_hi,
                   void* dst_dev, void* stream);
+
+/* ---- mel filterbank (BASELINE cfg3; NOT in the reference: definition is this library's own) ---- */
+/*
+ * HTK mel scale m = 2595*log10(1 + f/700), n_mels triangular filters with peak 1 (no area normalisation)
+ * between fmin and fmax, evaluated at the nfft/2+1 bin frequencies k*fs/nfft.  Writes the dense weight
+ * matrix weights_host[n_bins][n_mels] (row-major doubles); the caller uploads it in the plan's dtype.
+ */
+int sg_mel_weights(int nfft, double fs, int n_mels, double fmin, double fmax, double* weights_host);
+/* Per tile of 16 mel bands t: the bin range [k_lo[t], k_hi[t]) (multiples of 4) outside which every weight of the
+ * tile is zero (block sparsity of the triangular bank).  ceil(n_mels/16) entries each. */
+int sg_mel_tile_ranges(const double* weights_host, int n_bins, int n_mels, int* k_lo, int* k_hi);
+/*
+ * mel_dev[n_frames][n_mels] = spec_dev[n_frames][n_bins] x weights_dev[n_bins][n_mels]   (f32, contraction on the
+ * matrix cores: v_mfma_f32_16x16x4_f32, exact f32 FMA chain); tile_k_lo/hi from sg_mel_tile_ranges (host arrays,
+ * NULL = dense); log_scale != 0 applies 10*log10(max(x, 1e-10)).  n_mels <= 128.  Asynchronous.
+ */
+int sg_mel(const float* spec_dev, int64_t n_frames, int n_bins, const float* weights_dev, int n_mels,
+           const int* tile_k_lo, const int* tile_k_hi, int log_scale, float* mel_dev, void* stream);
 
 /* ---- timing helper used by bench.py (HIP events on `stream`) ---------- */
 /* Runs sg_stft `iters` times back to back between two hipEvents and returns the

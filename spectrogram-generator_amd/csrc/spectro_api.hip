@@ -174,6 +174,10 @@ int sg_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* strea
     if (bytes) SG_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
     return SG_OK;
 }
+int sg_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes, void* stream) {
+    if (bytes) SG_HIP(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+    return SG_OK;
+}
 int sg_memset(void* dst_dev, int value, size_t bytes, void* stream) {
     if (bytes) SG_HIP(hipMemsetAsync(dst_dev, value, bytes, static_cast<hipStream_t>(stream)));
     return SG_OK;

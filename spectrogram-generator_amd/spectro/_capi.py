@@ -36,6 +36,7 @@ SIGNATURES = {
     "sg_host_free": (_i, [_vp]),
     "sg_memcpy_h2d": (_i, [_vp, _vp, _sz, _vp]),
     "sg_memcpy_d2h": (_i, [_vp, _vp, _sz, _vp]),
+    "sg_memcpy_d2d": (_i, [_vp, _vp, _sz, _vp]),
     "sg_memset": (_i, [_vp, _i, _sz, _vp]),
     "sg_stream_create": (_i, [_pvp]),
     "sg_stream_destroy": (_i, [_vp]),
@@ -58,6 +59,9 @@ SIGNATURES = {
     "sg_band_sum": (_i, [_vp, _i, _i64, _i, _i, _i, _vp, _vp]),
     "sg_band_totals": (_i, [_vp, _i, _i64, _i, _i, C.POINTER(_i), C.POINTER(_i), _vp, _vp]),
     "sg_slice_bins": (_i, [_vp, _i, _i64, _i, _i, _i, _vp, _vp]),
+    "sg_mel_weights": (_i, [_i, _d, _i, _d, _d, C.POINTER(_d)]),
+    "sg_mel_tile_ranges": (_i, [C.POINTER(_d), _i, _i, C.POINTER(_i), C.POINTER(_i)]),
+    "sg_mel": (_i, [_vp, _i64, _i, _vp, _i, C.POINTER(_i), C.POINTER(_i), _i, _vp, _vp]),
     "sg_time_stft": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _i64, _vp, _i, C.POINTER(C.c_float)]),
 }
 

@@ -1,0 +1,65 @@
+"""Mel filterbank epilogue (BASELINE cfg3) -- an ADDITION: the reference has no mel stage.
+
+Definition (this library's own, see include/spectro.h): HTK mel scale, triangular unit-peak filters between
+``fmin`` and ``fmax`` at the rfft bin frequencies.  The contraction ``[frames, bins] x [bins, mels]`` runs on the
+matrix cores (exact-f32 MFMA) and skips the all-zero blocks of the triangular bank.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+__all__ = ["MelBank"]
+
+
+class MelBank:
+    """Device-resident filterbank for one (nfft, fs, n_mels, fmin, fmax)."""
+
+    def __init__(self, nfft: int, fs: float, n_mels: int = 80, fmin: float = 0.0, fmax: float | None = None):
+        _capi.ensure_device()
+        self.nfft, self.fs, self.n_mels = int(nfft), float(fs), int(n_mels)
+        self.n_bins = self.nfft // 2 + 1
+        self.fmin, self.fmax = float(fmin), float(fs / 2 if fmax is None else fmax)
+        w = np.empty((self.n_bins, self.n_mels), np.float64)
+        _capi.check(_capi.lib().sg_mel_weights(self.nfft, self.fs, self.n_mels, self.fmin, self.fmax,
+                                               w.ctypes.data_as(C.POINTER(C.c_double))))
+        self.weights = w
+        n_tiles = (self.n_mels + 15) // 16
+        self._k_lo, self._k_hi = (C.c_int * n_tiles)(), (C.c_int * n_tiles)()
+        _capi.check(_capi.lib().sg_mel_tile_ranges(w.ctypes.data_as(C.POINTER(C.c_double)), self.n_bins, self.n_mels,
+                                                   self._k_lo, self._k_hi))
+        w32 = np.ascontiguousarray(w, np.float32)
+        self._dev = _capi.DeviceBuffer(w32.nbytes)
+        self._dev.upload(w32)
+        _capi.stream_sync()
+
+    @property
+    def tile_ranges(self):
+        return list(zip(self._k_lo, self._k_hi))
+
+    def apply_ptr(self, spec_ptr: int, n_rows: int, out_ptr: int, log_scale: bool = False, dense: bool = False, stream=None):
+        """``out[n_rows][n_mels] = spec[n_rows][n_bins] x W`` on raw device pointers (f32); asynchronous."""
+        _capi.check(_capi.lib().sg_mel(C.c_void_p(spec_ptr), int(n_rows), self.n_bins, C.c_void_p(self._dev.ptr), self.n_mels,
+                                       None if dense else self._k_lo, None if dense else self._k_hi, int(bool(log_scale)),
+                                       C.c_void_p(out_ptr), C.c_void_p(stream)))
+
+    def apply(self, dev_spec, log_scale: bool = False, dense: bool = False):
+        """Mel spectrogram of a ``DeviceSpectrogram`` (f32) -> host array ``[..., n_mels, n_frames]``."""
+        if dev_spec.dtype_code != _capi.F32 or dev_spec.n_bins != self.n_bins:
+            raise ValueError("mel needs an f32 spectrum with nfft//2+1 bins of this bank")
+        out = np.empty((dev_spec.n_clips, dev_spec.n_frames, self.n_mels), np.float32)
+        if out.size:
+            d = _capi.DeviceBuffer(out.nbytes)
+            try:
+                self.apply_ptr(dev_spec.buf.ptr, dev_spec.rows, d.ptr, log_scale, dense)
+                d.download(out)
+                _capi.stream_sync()
+            finally:
+                d.free()
+        return np.moveaxis(out.reshape(*dev_spec.outer, dev_spec.n_frames, self.n_mels), -1, -2)
+
+    def close(self):
+        self._dev.free()

@@ -139,3 +139,60 @@ def test_device_epilogues_vs_oracle_f32_batch():
     sd = s.astype(np.float64)
     assert np.allclose(tot, [sd.sum(), sd[:, 10:20].sum(), 0.0, sd[:, 500:513].sum()], rtol=1e-5)
     dev.free()
+
+
+def test_mel_epilogue_vs_own_oracle():
+    """cfg3: 80-band mel of the PSD.  No reference behaviour exists (parity unpinned): checked against
+    oracle/mel_oracle.py, the numpy restatement of this library's own definition.  Asymmetric data so that a
+    transposed MFMA operand or accumulator map cannot pass."""
+    from oracle import mel_oracle
+    from spectro import engine
+    from spectro.mel import MelBank
+    rng = np.random.default_rng(21)
+    x = (rng.standard_normal((2, 30000)) * np.linspace(0.05, 1.0, 30000)).astype(np.float32)
+    dev = engine.stft(x, fs=48000.0, nperseg=1024, window="hann", noverlap=768)
+    bank = MelBank(1024, 48000.0, 80, 20.0, 20000.0)
+    w = mel_oracle.mel_weights(1024, 48000.0, 80, 20.0, 20000.0)
+    assert np.abs(bank.weights - w).max() < 1e-12
+    assert all(lo % 4 == 0 and hi % 4 == 0 and lo < hi for lo, hi in bank.tile_ranges)
+    s = np.moveaxis(dev.to_host(), -1, -2)                    # [clip, frame, bin]
+    for log in (False, True):
+        ref = np.moveaxis(mel_oracle.mel_spectrogram(s, w.astype(np.float32), log), -1, -2)
+        for dense in (False, True):
+            got = bank.apply(dev, log_scale=log, dense=dense)
+            assert got.shape == ref.shape == (2, 80, dev.n_frames)
+            if log:
+                assert np.abs(got - ref).max() < 1e-3          # dB
+            else:
+                assert np.abs(got - ref).max() <= 2e-6 * ref.max() and np.allclose(got, ref, rtol=2e-5, atol=1e-6 * ref.max())
+    # odd sizes: 37 mel bands on a 513-bin spectrum with 1 clip / frames not a multiple of 16
+    dev2 = engine.stft(x[0, :9000], fs=48000.0, nperseg=1024, window="hann", noverlap=512)
+    bank2 = MelBank(1024, 48000.0, 37)
+    ref2 = (np.moveaxis(dev2.to_host(), -1, -2).astype(np.float64) @ bank2.weights.astype(np.float32)).T
+    got2 = bank2.apply(dev2)
+    assert got2.shape == ref2.shape and np.allclose(got2, ref2, rtol=2e-5, atol=1e-6 * ref2.max())
+    dev.free(); dev2.free(); bank.close(); bank2.close()
+
+
+@pytest.mark.parametrize("nperseg,hop,n_ch,fs", [(4096, 1024, 8, 96000.0), (1024, 256, 3, 48000.0), (256, 224, 2, 500.0)])
+def test_streaming_equals_offline(nperseg, hop, n_ch, fs):
+    """cfg5: feeding chunks (4096 samples/channel, plus ragged sizes) yields exactly the offline frames."""
+    import spectro
+    from spectro.stream import StreamingSTFT
+    rng = np.random.default_rng(nperseg)
+    total = nperseg * 6 + 777
+    x = (rng.standard_normal((n_ch, total)) * 0.3).astype(np.float32)
+    st = StreamingSTFT(n_ch, fs, nperseg, hop, window="hann")
+    chunks = [4096, 1, 4096, 313, 0, 4096, 5000]
+    pos, ts, outs = 0, [], []
+    while pos < total:
+        n = min(chunks[len(ts) % len(chunks)], total - pos)
+        t, s = st.feed(x[:, pos:pos + n])
+        ts.append(t); outs.append(s)
+        pos += n
+    t_all, s_all = np.concatenate(ts), np.concatenate(outs, axis=-1)
+    f, t_ref, s_ref = spectro.spectrogram(x, fs=fs, nperseg=nperseg, window="hann", noverlap=nperseg - hop)
+    assert s_all.shape == s_ref.shape
+    np.testing.assert_array_equal(t_all, t_ref)
+    np.testing.assert_array_equal(s_all, s_ref)               # same kernel, same samples -> bit-identical
+    st.close()

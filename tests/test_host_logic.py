@@ -277,3 +277,22 @@ def test_gloo_world2_sharding(tmp_path):
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+
+
+def test_mel_weights_host_function_matches_own_oracle():
+    import ctypes as C
+    from oracle import mel_oracle
+    from spectro import _capi
+    for nfft, fs, nm, lo, hi in [(1024, 48000.0, 80, 0.0, 24000.0), (512, 16000.0, 40, 50.0, 7600.0), (4096, 96000.0, 128, 20.0, 20000.0)]:
+        w = np.empty((nfft // 2 + 1, nm))
+        _capi.check(_capi.lib().sg_mel_weights(nfft, fs, nm, lo, hi, w.ctypes.data_as(C.POINTER(C.c_double))))
+        ref = mel_oracle.mel_weights(nfft, fs, nm, lo, hi)
+        assert np.abs(w - ref).max() < 1e-12
+        assert w.min() >= 0 and w.max() <= 1.0 + 1e-12
+        nt = (nm + 15) // 16
+        klo, khi = (C.c_int * nt)(), (C.c_int * nt)()
+        _capi.check(_capi.lib().sg_mel_tile_ranges(w.ctypes.data_as(C.POINTER(C.c_double)), nfft // 2 + 1, nm, klo, khi))
+        for t in range(nt):
+            blk = w[:, 16 * t:16 * t + 16]
+            nz = np.nonzero(blk.any(axis=1))[0]
+            assert klo[t] <= nz[0] and khi[t] >= nz[-1] + 1 and klo[t] % 4 == 0 and khi[t] % 4 == 0
