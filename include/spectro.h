@@ -102,7 +102,7 @@ int sg_plan_n_frames(const sg_plan* plan, int64_t n_samples, int64_t* n_frames);
 int sg_plan_n_bins(const sg_plan* plan, int* n_bins);
 /* the scale factor the kernels multiply |X|^2 with (as double) */
 int sg_plan_scale(const sg_plan* plan, double* scale);
-/* name of the kernel family the plan dispatches to: "r8x3", "stockham", "bluestein" */
+/* name of the kernel family the plan dispatches to: "r8x3", "rsmall", "stockham", "bluestein" */
 const char* sg_plan_kernel(const sg_plan* plan);
 /* Tests / benchmarks: route the plan to another family that can run it ("stockham" for an
  * r8x3 plan).  SG_ERR_UNSUPPORTED if that family cannot run this plan. */
@@ -173,8 +173,11 @@ int sg_mel_weights(int nfft, double fs, int n_mels, double fmin, double fmax, do
 /* Per tile of 16 mel bands t: the bin range [k_lo[t], k_hi[t]) (multiples of 4) outside which every weight of the
  * tile is zero (block sparsity of the triangular bank).  ceil(n_mels/16) entries each. */
 int sg_mel_tile_ranges(const double* weights_host, int n_bins, int n_mels, int* k_lo, int* k_hi);
+/* Device layout of the bank: transposed and zero padded, packed_host[16*ceil(n_mels/16)][round_up(n_bins,16)] f32
+ * (bin index contiguous), so that both MFMA operands are fetched as aligned 16-byte vectors. */
+int sg_mel_pack_weights(const double* weights_host, int n_bins, int n_mels, float* packed_host);
 /*
- * mel_dev[n_frames][n_mels] = spec_dev[n_frames][n_bins] x weights_dev[n_bins][n_mels]   (f32, contraction on the
+ * mel_dev[n_frames][n_mels] = spec_dev[n_frames][n_bins] x W   (weights_dev = sg_mel_pack_weights layout; f32, contraction on the
  * matrix cores: v_mfma_f32_16x16x4_f32, exact f32 FMA chain); tile_k_lo/hi from sg_mel_tile_ranges (host arrays,
  * NULL = dense); log_scale != 0 applies 10*log10(max(x, 1e-10)).  n_mels <= 128.  Asynchronous.
  */

@@ -21,13 +21,19 @@ struct MelParams {
     const float* spec;       // [n_frames][n_bins]
     int64_t n_frames;
     int n_bins, n_mels, n_tiles, log_scale;
-    const float* w;          // [n_bins][n_mels]
+    const float* wt;         // transposed, padded: [16*n_tiles][k_pad]  (k contiguous, zero padded)
+    int k_pad;               // n_bins rounded up to a multiple of 16
     float* out;              // [n_frames][n_mels]
-    int k_lo[kMaxTiles], k_hi[kMaxTiles];   // per mel tile: k range (multiples of 4, hi exclusive) with non-zero weights
+    int k_lo[kMaxTiles], k_hi[kMaxTiles];   // per mel tile: k range (multiples of 16, hi exclusive) with non-zero weights
 };
 
-// One wavefront per 16 consecutive frames.  A operand: S[f0 + (l&15)][k0 + (l>>4)], B operand:
-// W[k0 + (l>>4)][16*t + (l&15)], accumulator: col = l&15 (mel), row = 4*(l>>4) + reg (frame).
+// One wavefront per 16 consecutive frames.  The contraction index is consumed 16 at a time: lane (i = l&15,
+// kq = l>>4) loads the spectrum row f0+i at k = 16j + 4kq .. +3 ONCE and, for every mel tile whose triangles
+// cover this k block, ONE float4 of the transposed weights of mel column 16t+i at the same k; MFMA step e
+// multiplies element e of both.  Any bijection between (step, kq) and k is a valid order for the sum as long as
+// A and B agree, so no cross-lane shuffle is needed.  All NT tile accumulators stay live, so the spectrum is read
+// from HBM exactly once.  Accumulator map: col = l&15 (mel), row = 4*(l>>4) + reg (frame).
+template <int NT>
 __global__ __launch_bounds__(256) void mel_kernel(const MelParams p) {
     const int lane = threadIdx.x & 63;
     const int64_t tile = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
@@ -36,30 +42,53 @@ __global__ __launch_bounds__(256) void mel_kernel(const MelParams p) {
     const int i = lane & 15, kq = lane >> 4;
     int64_t fa = f0 + i;
     if (fa >= p.n_frames) fa = p.n_frames - 1;           // clamp: rows past the end are computed but not stored
-    const float* const arow = p.spec + fa * p.n_bins;
-    for (int t = 0; t < p.n_tiles; ++t) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const int col = 16 * t + i;
-        const bool col_ok = col < p.n_mels;
-        for (int k0 = p.k_lo[t]; k0 < p.k_hi[t]; k0 += 4) {
-            const int k = k0 + kq;
-            const bool k_ok = k < p.n_bins;
-            const float a = k_ok ? arow[k] : 0.f;
-            const float b = (k_ok && col_ok) ? p.w[static_cast<int64_t>(k) * p.n_mels + col] : 0.f;
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    const float* const arow = p.spec + fa * p.n_bins + 4 * kq;
+    const float* const wrow = p.wt + static_cast<int64_t>(i) * p.k_pad + 4 * kq;
+    const int k_last = p.n_bins - 1 - 4 * kq;            // last valid index relative to arow
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int k_full = (p.n_bins - 16) & ~15;            // blocks below this never touch the row end
+#pragma unroll 2
+    for (int k0 = 0; k0 < p.k_pad; k0 += 16) {
+        f32x4 a;
+        if (k0 < k_full) {
+            a = f32x4{arow[k0], arow[k0 + 1], arow[k0 + 2], arow[k0 + 3]};     // rows are only 4-byte aligned (n_bins odd)
+        } else {   // tail of the row: clamp (the padded weights are zero there)
+            a = f32x4{arow[min(k0, k_last)], arow[min(k0 + 1, k_last)], arow[min(k0 + 2, k_last)], arow[min(k0 + 3, k_last)]};
         }
-        if (col_ok) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (k0 >= p.k_lo[t] && k0 < p.k_hi[t]) {      // wave-uniform: block sparsity of the triangular bank
+                const f32x4 b = *reinterpret_cast<const f32x4*>(wrow + static_cast<int64_t>(16 * t) * p.k_pad + k0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc[t], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int col = 16 * t + i;
+        if (col < p.n_mels) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t f = f0 + 4 * kq + r;
                 if (f < p.n_frames) {
-                    float v = acc[r];
+                    float v = acc[t][r];
                     if (p.log_scale) v = 10.0f * log10f(fmaxf(v, 1e-10f));
                     p.out[f * p.n_mels + col] = v;
                 }
             }
         }
     }
+}
+
+template <int NT>
+void launch_mel(const MelParams& p, unsigned grid, hipStream_t s) {
+    hipLaunchKernelGGL(mel_kernel<NT>, dim3(grid), dim3(256), 0, s, p);
 }
 
 }  // namespace
@@ -92,6 +121,16 @@ int sg_mel_weights(int nfft, double fs, int n_mels, double fmin, double fmax, do
     return SG_OK;
 }
 
+int sg_mel_pack_weights(const double* weights_host, int n_bins, int n_mels, float* packed_host) {
+    if (!weights_host || !packed_host || n_bins < 1 || n_mels < 1) { set_error("bad argument"); return SG_ERR_ARG; }
+    const int k_pad = (n_bins + 15) & ~15, m_pad = ((n_mels + 15) / 16) * 16;
+    for (int m = 0; m < m_pad; ++m)
+        for (int k = 0; k < k_pad; ++k)
+            packed_host[static_cast<size_t>(m) * k_pad + k] =
+                (m < n_mels && k < n_bins) ? static_cast<float>(weights_host[static_cast<size_t>(k) * n_mels + m]) : 0.f;
+    return SG_OK;
+}
+
 int sg_mel_tile_ranges(const double* weights_host, int n_bins, int n_mels, int* k_lo, int* k_hi) {
     if (!weights_host || !k_lo || !k_hi || n_bins < 1 || n_mels < 1) { set_error("bad argument"); return SG_ERR_ARG; }
     const int n_tiles = (n_mels + 15) / 16;
@@ -115,14 +154,26 @@ int sg_mel(const float* spec_dev, int64_t n_frames, int n_bins, const float* wei
     auto s = static_cast<hipStream_t>(stream);
     MelParams p{};
     p.spec = spec_dev; p.n_frames = n_frames; p.n_bins = n_bins; p.n_mels = n_mels;
-    p.n_tiles = (n_mels + 15) / 16; p.log_scale = log_scale; p.w = weights_dev; p.out = mel_dev;
+    p.n_tiles = (n_mels + 15) / 16; p.log_scale = log_scale; p.wt = weights_dev; p.out = mel_dev;
+    p.k_pad = (n_bins + 15) & ~15;
     for (int t = 0; t < p.n_tiles; ++t) {
-        p.k_lo[t] = tile_k_lo ? tile_k_lo[t] & ~3 : 0;
-        p.k_hi[t] = tile_k_hi ? (tile_k_hi[t] + 3) & ~3 : (n_bins + 3) & ~3;
+        p.k_lo[t] = tile_k_lo ? tile_k_lo[t] & ~15 : 0;
+        p.k_hi[t] = tile_k_hi ? (tile_k_hi[t] + 15) & ~15 : p.k_pad;
         if (p.k_lo[t] < 0) p.k_lo[t] = 0;
+        if (p.k_hi[t] > p.k_pad) p.k_hi[t] = p.k_pad;
     }
     const int64_t tiles = (n_frames + 15) / 16;
-    hipLaunchKernelGGL(mel_kernel, dim3(static_cast<unsigned>((tiles + 3) / 4)), dim3(256), 0, s, p);
+    const unsigned grid = static_cast<unsigned>((tiles + 3) / 4);
+    switch (p.n_tiles) {
+        case 1: launch_mel<1>(p, grid, s); break;
+        case 2: launch_mel<2>(p, grid, s); break;
+        case 3: launch_mel<3>(p, grid, s); break;
+        case 4: launch_mel<4>(p, grid, s); break;
+        case 5: launch_mel<5>(p, grid, s); break;
+        case 6: launch_mel<6>(p, grid, s); break;
+        case 7: launch_mel<7>(p, grid, s); break;
+        default: launch_mel<8>(p, grid, s); break;
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "mel launch");
     return SG_OK;

@@ -19,7 +19,7 @@ int hip_fail(hipError_t e, const char* what);   // records message, returns SG_E
         if (e__ != hipSuccess) return ::sg::hip_fail(e__, #call);      \
     } while (0)
 
-enum class Kernel { R8X3, STOCKHAM, BLUESTEIN };
+enum class Kernel { R8X3, RSMALL, STOCKHAM, BLUESTEIN };
 
 }  // namespace sg
 
@@ -35,7 +35,7 @@ struct sg_plan {
     // device tables
     void* win_dev = nullptr;     // nperseg reals of dtype
     void* tw_dev = nullptr;      // nfft/2 complex of dtype: exp(-2*pi*i*k/nfft), k < nfft/2
-    void* r8_tw_dev = nullptr;   // R8X3 only: [18][64] float2 per-lane twiddles
+    void* r8_tw_dev = nullptr;   // R8X3: [18][64], RSMALL: [(R-1)+11][64] float2 per-lane twiddles
     // Bluestein tables (complex of dtype)
     int bs_len = 0;              // padded pow2 length L >= 2*nfft-1
     void* bs_chirp_dev = nullptr;   // b[n] = exp(-i*pi*n^2/nfft), n < nfft
@@ -56,10 +56,13 @@ struct StftArgs {
 };
 
 int launch_r8x3(const sg_plan& p, const StftArgs& a);
+int launch_rsmall(const sg_plan& p, const StftArgs& a);
+bool rsmall_can_run(const sg_plan& p, const StftArgs& a);
 int launch_stockham(const sg_plan& p, const StftArgs& a);
 int launch_bluestein(const sg_plan& p, const StftArgs& a);
 
 int build_r8x3_tables(sg_plan& p, const std::vector<double>& window);
+int build_rsmall_tables(sg_plan& p);
 int build_bluestein_tables(sg_plan& p);
 
 }  // namespace sg

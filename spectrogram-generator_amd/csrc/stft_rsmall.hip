@@ -1,0 +1,245 @@
+// stft_rsmall.hip -- register FFT kernel for the small transforms of the parameter sweep (BASELINE cfg4):
+// nperseg = nfft = 128*R with R = 2 (256) or R = 4 (512), f32, detrend none|constant, psd|magnitude.
+//
+// Same machine mapping as stft_r8x3.hip (one wavefront, 8 complex values per lane, three register passes, two
+// padded LDS transposes, split pass with only the upper half crossing lanes, no s_barrier in the frame loop), but a
+// wave carries G = 8/R frames at once so that all 64 lanes stay busy:
+//   pass 1: lane j holds z_g[j + 64a] (a < R) of every frame g -> G independent R-point DFTs, twiddle w_M^(j*r)
+//   pass 2/3: the radix-8 passes of the 1024 kernel with the register index v = g*R + r
+//   after pass 3 lane l = lu + L*g (L = 8R lanes per frame) holds Z_g[lu + L*t], t = 0..7.
+// Index maps and LDS bank behaviour are replayed in tools/sim_rsmall.py.
+// Algorithmic HBM bytes per frame: hop*4 + (64R+1)*4.
+#include "spectro_internal.h"
+#include "fft_wave.h"
+
+#include <cmath>
+#include <cstdlib>
+
+namespace sg {
+namespace {
+
+using namespace wavefft;
+
+constexpr int kS1 = 72, kS2 = 66, kSlab = 8 * kS1, kWaves = 4;
+
+struct SmallParams {
+    const float* x;
+    int64_t clip_stride;
+    int n_frames, hop;
+    int groups_per_clip;      // ceil(n_frames / G)
+    int64_t total_groups;
+    int n_waves;
+    float* out;
+    int64_t out_clip_stride;
+    const float2* win2;       // [M] pairs (w[2n], w[2n+1])
+    const float2* tw;         // [(R-1) + 7 + 4][64]
+    float scale;
+};
+
+template <int R> __device__ __forceinline__ void radix_small(float2* a);
+template <> __device__ __forceinline__ void radix_small<2>(float2* a) {
+    const float2 s = cadd(a[0], a[1]), d = csub(a[0], a[1]);
+    a[0] = s; a[1] = d;
+}
+template <> __device__ __forceinline__ void radix_small<4>(float2* a) {
+    const float2 s02 = cadd(a[0], a[2]), d02 = csub(a[0], a[2]);
+    const float2 s13 = cadd(a[1], a[3]), d13 = mul_mi(csub(a[1], a[3]));
+    a[0] = cadd(s02, s13); a[2] = csub(s02, s13);
+    a[1] = cadd(d02, d13); a[3] = csub(d02, d13);
+}
+
+template <int R, bool DETREND, int MODE>
+__global__ __launch_bounds__(64 * kWaves) void stft_rsmall_kernel(const SmallParams p) {
+    constexpr int G = 8 / R, M = 64 * R, L = 8 * R, NB = M + 1, RS = M + 8;
+    static_assert(G * RS <= kSlab, "split regions must fit the slab");
+    __shared__ __attribute__((aligned(16))) float2 lds[kWaves * kSlab];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float2* const buf = lds + wave * kSlab;
+
+    const int lw = xcd_remap(blockIdx.x, gridDim.x) * kWaves + wave;
+    if (lw >= p.n_waves) return;
+    int64_t q = p.total_groups * lw / p.n_waves;
+    const int64_t q_end = p.total_groups * (lw + 1) / p.n_waves;
+
+    // per-lane constants
+    float2 w[R], t1[R - 1], t2[7], t3[4];
+#pragma unroll
+    for (int a = 0; a < R; ++a) w[a] = p.win2[lane + 64 * a];
+#pragma unroll
+    for (int r = 0; r < R - 1; ++r) t1[r] = p.tw[r * 64 + lane];
+#pragma unroll
+    for (int s = 0; s < 7; ++s) t2[s] = p.tw[(R - 1 + s) * 64 + lane];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) t3[t] = p.tw[(R - 1 + 7 + t) * 64 + lane];
+
+    const int j0 = lane & 7, v_ = lane >> 3;
+    float2* const x1w = buf + v_ * kS1 + j0;                          // + 8*v      (v_ here is b = lane>>3)
+    float2* const x1r = buf + lane;                                   // + b*kS1
+    float2* const x2w = buf + j0 * kS2 + (v_ % R) + L * (v_ / R);     // + R*s      (v_ here is v = g*R + r)
+    float2* const x2r = buf + lane;                                   // + j0*kS2
+    const int g3 = lane / L, lu = lane - g3 * L;
+    float2* const x3w = buf + g3 * RS + lu;                           // + L*t
+    const float2* const x3b = buf + g3 * RS + (M - lu);               // - L*t
+
+    const float q_in = MODE == 0 ? p.scale * 0.5f : p.scale * 0.25f;
+    const float q0 = lu == 0 ? p.scale * 0.25f : q_in;
+
+    for (; q < q_end; ++q) {
+        const int clip = static_cast<int>(q / p.groups_per_clip);
+        const int fg = static_cast<int>(q - static_cast<int64_t>(clip) * p.groups_per_clip) * G;
+        const float* const xclip = p.x + static_cast<int64_t>(clip) * p.clip_stride + 2 * lane;
+
+        float2 a[8];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int f = min(fg + g, p.n_frames - 1);                 // partial last group: recompute the last frame
+            const float* const src = xclip + static_cast<int64_t>(f) * p.hop;
+#pragma unroll
+            for (int k = 0; k < R; ++k) a[g * R + k] = *reinterpret_cast<const float2*>(src + 128 * k);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (DETREND) {
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < R; ++k) s += a[g * R + k].x + a[g * R + k].y;
+                const float mean = wave_sum(s) * (1.0f / (2 * M));
+#pragma unroll
+                for (int k = 0; k < R; ++k) { a[g * R + k].x -= mean; a[g * R + k].y -= mean; }
+            }
+#pragma unroll
+            for (int k = 0; k < R; ++k) { a[g * R + k].x *= w[k].x; a[g * R + k].y *= w[k].y; }
+            radix_small<R>(a + g * R);
+#pragma unroll
+            for (int r = 1; r < R; ++r) a[g * R + r] = cmul(a[g * R + r], t1[r - 1]);
+        }
+#pragma unroll
+        for (int v = 0; v < 8; ++v) lds_put(x1w + 8 * v, a[v]);
+        wave_lds_fence();
+#pragma unroll
+        for (int b = 0; b < 8; ++b) a[b] = lds_get(x1r + b * kS1);
+        wave_lds_fence();
+
+        radix8(a);
+#pragma unroll
+        for (int s = 1; s < 8; ++s) a[s] = cmul(a[s], t2[s - 1]);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) lds_put(x2w + R * s, a[s]);
+        wave_lds_fence();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = lds_get(x2r + j * kS2);
+        wave_lds_fence();
+
+        radix8(a);
+#pragma unroll
+        for (int t = 4; t < 8; ++t) lds_put(x3w + L * t, a[t]);
+        if (lu == 0) lds_put(buf + g3 * RS + M, a[0]);                 // Z_g[M] := Z_g[0]
+        wave_lds_fence();
+
+        const int f = fg + g3;
+        const bool live = f < p.n_frames;
+        float* const orow = p.out + static_cast<int64_t>(clip) * p.out_clip_stride + static_cast<int64_t>(min(f, p.n_frames - 1)) * NB;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float2 A = a[t];
+            const float2 B = lds_get(x3b - L * t);
+            const float2 cs = t3[t];
+            const float2 S = make_float2(A.x + B.x, A.y - B.y);
+            const float2 D = make_float2(A.x - B.x, A.y + B.y);
+            const float2 T = make_float2(fmaf(cs.y, D.x, -cs.x * D.y), fmaf(cs.x, D.x, cs.y * D.y));
+            const float2 Xk = csub(S, T), Xm = cadd(S, T);
+            const float qq = t == 0 ? q0 : q_in;
+            float pk = fmaf(Xk.x, Xk.x, Xk.y * Xk.y) * qq;
+            float pm = fmaf(Xm.x, Xm.x, Xm.y * Xm.y) * qq;
+            if (MODE == 1) { pk = sqrtf(pk); pm = sqrtf(pm); }
+            const int k = lu + L * t;
+            if (live) {
+                orow[k] = pk;
+                orow[M - k] = pm;
+            }
+        }
+        if (live && lu == 0) {                                         // k = M/2 pairs with itself: |Z[M/2]|^2
+            float pq = fmaf(a[4].x, a[4].x, a[4].y * a[4].y) * (q_in * 4.0f);
+            if (MODE == 1) pq = sqrtf(pq);
+            orow[M / 2] = pq;
+        }
+        wave_lds_fence();
+    }
+}
+
+template <int R, bool DETREND>
+int launch_rd(const SmallParams& prm, int n_wg, hipStream_t s, int mode) {
+    if (mode == SG_MODE_PSD) hipLaunchKernelGGL((stft_rsmall_kernel<R, DETREND, 0>), dim3(n_wg), dim3(64 * kWaves), 0, s, prm);
+    else hipLaunchKernelGGL((stft_rsmall_kernel<R, DETREND, 1>), dim3(n_wg), dim3(64 * kWaves), 0, s, prm);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SG_OK : hip_fail(e, "stft_rsmall launch");
+}
+
+template <int R>
+int launch_r(const sg_plan& p, const StftArgs& a) {
+    constexpr int G = 8 / R;
+    SmallParams prm{};
+    prm.x = static_cast<const float*>(a.x);
+    prm.clip_stride = a.clip_stride;
+    prm.n_frames = static_cast<int>(a.n_frames);
+    prm.hop = p.hop;
+    prm.groups_per_clip = static_cast<int>((a.n_frames + G - 1) / G);
+    prm.total_groups = static_cast<int64_t>(prm.groups_per_clip) * a.n_clips;
+    int64_t n_waves = static_cast<int64_t>(p.n_cu) * 4 * 4;
+    const int64_t by_work = (prm.total_groups + 1) / 2;
+    if (n_waves > by_work) n_waves = by_work;
+    if (n_waves < 1) n_waves = 1;
+    prm.n_waves = static_cast<int>(n_waves);
+    prm.out = static_cast<float*>(a.out);
+    prm.out_clip_stride = a.out_clip_stride;
+    prm.win2 = static_cast<const float2*>(p.win_dev);
+    prm.tw = static_cast<const float2*>(p.r8_tw_dev);
+    prm.scale = static_cast<float>(p.scale);
+    const int n_wg = static_cast<int>((n_waves + kWaves - 1) / kWaves);
+    return p.detrend == SG_DETREND_CONSTANT ? launch_rd<R, true>(prm, n_wg, a.stream, p.mode)
+                                            : launch_rd<R, false>(prm, n_wg, a.stream, p.mode);
+}
+
+}  // namespace
+
+// The register path needs 8-byte aligned float2 loads and writes whole spectra; everything else (int16 input, odd
+// hops, fused band sums) is served by the Stockham kernel of the same plan.
+bool rsmall_can_run(const sg_plan& p, const StftArgs& a) {
+    return !a.in_i16 && !a.band_mode && (p.hop % 2 == 0) && (a.clip_stride % 2 == 0 || a.n_clips == 1) &&
+           (reinterpret_cast<uintptr_t>(a.x) % 8 == 0) && a.n_frames <= INT32_MAX;
+}
+
+int launch_rsmall(const sg_plan& p, const StftArgs& a) {
+    if (a.n_frames <= 0 || a.n_clips <= 0) return SG_OK;
+    return p.nfft == 256 ? launch_r<2>(p, a) : launch_r<4>(p, a);
+}
+
+// Per-lane twiddle table [(R-1) + 7 + 4][64] float2 (R = nfft/128), computed in double:
+//   rows 0..R-2      t1[r-1][j] = exp(-2*pi*i*j*r/M)                  M = 64R
+//   rows R-1..R+5    t2[s-1][j] = exp(-2*pi*i*(j&7)*s/64)
+//   rows R+6..R+9    t3[t][j]   = (cos, sin)(2*pi*k/(2M)), k = (j % 8R) + 8R*t
+int build_rsmall_tables(sg_plan& p) {
+    const int R = p.nfft / 128, M = 64 * R, L = 8 * R;
+    std::vector<float2> tw(static_cast<size_t>(R - 1 + 7 + 4) * 64);
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int j = 0; j < 64; ++j) {
+        for (int r = 1; r < R; ++r) {
+            const double ang = -two_pi * static_cast<double>((j * r) % M) / M;
+            tw[(r - 1) * 64 + j] = make_float2(static_cast<float>(std::cos(ang)), static_cast<float>(std::sin(ang)));
+        }
+        for (int s = 1; s < 8; ++s) {
+            const double ang = -two_pi * static_cast<double>(((j & 7) * s) % 64) / 64.0;
+            tw[(R - 1 + s - 1) * 64 + j] = make_float2(static_cast<float>(std::cos(ang)), static_cast<float>(std::sin(ang)));
+        }
+        for (int t = 0; t < 4; ++t) {
+            const double ang = two_pi * static_cast<double>((j % L) + L * t) / (2.0 * M);
+            tw[(R - 1 + 7 + t) * 64 + j] = make_float2(static_cast<float>(std::cos(ang)), static_cast<float>(std::sin(ang)));
+        }
+    }
+    SG_HIP(hipMalloc(&p.r8_tw_dev, tw.size() * sizeof(float2)));
+    SG_HIP(hipMemcpy(p.r8_tw_dev, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
+    return SG_OK;
+}
+
+}  // namespace sg

@@ -31,9 +31,11 @@ class MelBank:
         self._k_lo, self._k_hi = (C.c_int * n_tiles)(), (C.c_int * n_tiles)()
         _capi.check(_capi.lib().sg_mel_tile_ranges(w.ctypes.data_as(C.POINTER(C.c_double)), self.n_bins, self.n_mels,
                                                    self._k_lo, self._k_hi))
-        w32 = np.ascontiguousarray(w, np.float32)
-        self._dev = _capi.DeviceBuffer(w32.nbytes)
-        self._dev.upload(w32)
+        packed = np.empty((16 * n_tiles, (self.n_bins + 15) // 16 * 16), np.float32)     # transposed + zero padded
+        _capi.check(_capi.lib().sg_mel_pack_weights(w.ctypes.data_as(C.POINTER(C.c_double)), self.n_bins, self.n_mels,
+                                                    packed.ctypes.data_as(C.POINTER(C.c_float))))
+        self._dev = _capi.DeviceBuffer(packed.nbytes)
+        self._dev.upload(packed)
         _capi.stream_sync()
 
     @property

@@ -32,7 +32,7 @@ class StreamingSTFT:
                              _capi.SCALING[scaling], _capi.MODE[mode], code)
         self.n_bins = self.plan.n_bins
         self.max_chunk = int(max_chunk)
-        self._stride = self.nperseg + self.hop + self.max_chunk          # samples per channel in the staging buffer
+        self._stride = (self.nperseg + self.hop + self.max_chunk + 1) & ~1   # samples per channel (even: keeps float2 loads aligned)
         isz = self.dtype.itemsize
         self._buf = _capi.DeviceBuffer(self.n_channels * self._stride * isz)
         self._tmp = _capi.DeviceBuffer(self.n_channels * (self.nperseg + self.hop) * isz)

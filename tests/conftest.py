@@ -50,12 +50,13 @@ def eeg_like():
     return x + 3.0
 
 
-def assert_spec_close(got, ref, tol_frame=1e-4, tol_norm=1e-5, bin_rtol=1e-4, time_axis=-1):
+def assert_spec_close(got, ref, tol_frame=1e-4, tol_norm=1e-5, bin_rtol=1e-4, time_axis=-1, bin_floor=1e-3):
     """The parity criterion of BASELINE.md §2 / SURVEY H2 for fp32 spectra.
 
     per frame: |got-ref| <= tol_frame * max_k ref[k];  normwise ||d||/||ref|| <= tol_norm;
     per-bin rtol only for bins >= 1e-3 * frame max (near-zero bins suffer cancellation in
-    fp32 for ANY implementation, scipy's own f32 path included).
+    fp32 for ANY implementation, scipy's own f32 path included).  For magnitude spectra pass
+    bin_floor=sqrt(1e-3): the same bins in power terms.
     """
     wide = np.complex128 if (np.iscomplexobj(got) or np.iscomplexobj(ref)) else np.float64
     got = np.asarray(got, wide)
@@ -71,7 +72,7 @@ def assert_spec_close(got, ref, tol_frame=1e-4, tol_norm=1e-5, bin_rtol=1e-4, ti
     nr = np.linalg.norm(r)
     if nr > 0:
         assert np.linalg.norm(g - r) / nr <= tol_norm, f"normwise {np.linalg.norm(g - r) / nr:.3e}"
-    big = (np.abs(r) >= 1e-3 * fmax) & (fmax > 0)
+    big = (np.abs(r) >= bin_floor * fmax) & (fmax > 0)
     if big.any():
         rel = d[big] / np.abs(r[big])
         assert rel.max() <= bin_rtol, f"per-bin rel {rel.max():.3e}"

