@@ -19,7 +19,7 @@ int hip_fail(hipError_t e, const char* what);   // records message, returns SG_E
         if (e__ != hipSuccess) return ::sg::hip_fail(e__, #call);      \
     } while (0)
 
-enum class Kernel { R8X3, RSMALL, STOCKHAM, BLUESTEIN };
+enum class Kernel { R8X3, RSMALL, RBIG, STOCKHAM, BLUESTEIN };
 
 }  // namespace sg
 
@@ -58,11 +58,14 @@ struct StftArgs {
 int launch_r8x3(const sg_plan& p, const StftArgs& a);
 int launch_rsmall(const sg_plan& p, const StftArgs& a);
 bool rsmall_can_run(const sg_plan& p, const StftArgs& a);
+int launch_rbig(const sg_plan& p, const StftArgs& a);
+bool rbig_can_run(const sg_plan& p, const StftArgs& a);
 int launch_stockham(const sg_plan& p, const StftArgs& a);
 int launch_bluestein(const sg_plan& p, const StftArgs& a);
 
 int build_r8x3_tables(sg_plan& p, const std::vector<double>& window);
 int build_rsmall_tables(sg_plan& p);
+int build_rbig_tables(sg_plan& p);
 int build_bluestein_tables(sg_plan& p);
 
 }  // namespace sg

@@ -1,0 +1,295 @@
+// stft_rbig.hip -- register FFT kernel for the large transforms of the parameter sweep (BASELINE cfg4):
+// nperseg = nfft = 1024*T with T = 2 (2048) or T = 4 (4096), f32, detrend none|constant, psd|magnitude.
+//
+// One wavefront = one frame; the packed signal has M = 512*T complex points, lane j keeps z[j + 64a] for
+// a < R = 8T in VGPRs (d[a0][a1], a = a0 + T*a1).  Three register passes, two padded LDS transposes:
+//   pass 1: R-point DFT in registers = T radix-8 butterflies over a1, constant twiddles w_R^(a0*r1), 8 radix-T
+//           butterflies over a0; then the lane twiddle w_M^(j*r)              (r = r1 + 8*r0 lives in d[r0][r1])
+//   pass 2: lane j0 + 8*r1 runs T radix-8 butterflies over b (j = j0 + 8b), twiddle w_64^(j0*s)
+//   pass 3: lane l runs T radix-8 butterflies over j0 and ends with Z[l + 64c], c = q3 + T*t in d[q3][t]
+// and the split pass pairs k = l + 64c (c < R/2, registers) with M - k (upper half, through LDS).
+// Window and twiddle tables live in LDS (one copy per workgroup).  Index maps and bank behaviour: tools/sim_rbig.py.
+// Algorithmic HBM bytes per frame: hop*4 + (512T+1)*4.
+#include "spectro_internal.h"
+#include "fft_wave.h"
+
+#include <cmath>
+#include <cstdlib>
+
+namespace sg {
+namespace {
+
+using namespace wavefft;
+
+constexpr int kS1 = 72, kS2 = 66, kWaves = 4;
+
+struct BigParams {
+    const float* x;
+    int64_t clip_stride;
+    int n_frames, hop;
+    int64_t total_frames;
+    int n_waves;
+    float* out;
+    int64_t out_clip_stride;
+    const float2* win2;       // [M]
+    const float2* tw;         // [(R-1) + 7 + R/2][64]
+    float scale;
+};
+
+template <int T> __device__ __forceinline__ void radix_t(float2 (&v)[T]);
+template <> __device__ __forceinline__ void radix_t<2>(float2 (&v)[2]) {
+    const float2 s = cadd(v[0], v[1]), d = csub(v[0], v[1]);
+    v[0] = s; v[1] = d;
+}
+template <> __device__ __forceinline__ void radix_t<4>(float2 (&v)[4]) {
+    const float2 s02 = cadd(v[0], v[2]), d02 = csub(v[0], v[2]);
+    const float2 s13 = cadd(v[1], v[3]), d13 = mul_mi(csub(v[1], v[3]));
+    v[0] = cadd(s02, s13); v[2] = csub(s02, s13);
+    v[1] = cadd(d02, d13); v[3] = csub(d02, d13);
+}
+
+// exp(-2*pi*i*n/R) for the in-register twiddles of pass 1; indices are compile-time after unrolling, so these
+// fold into instruction immediates.
+__device__ constexpr float kW16[16][2] = {{1.000000000e+00f, -0.000000000e+00f}, {9.238795325e-01f, -3.826834324e-01f}, {7.071067812e-01f, -7.071067812e-01f}, {3.826834324e-01f, -9.238795325e-01f}, {6.123233996e-17f, -1.000000000e+00f}, {-3.826834324e-01f, -9.238795325e-01f}, {-7.071067812e-01f, -7.071067812e-01f}, {-9.238795325e-01f, -3.826834324e-01f}, {-1.000000000e+00f, -1.224646799e-16f}, {-9.238795325e-01f, 3.826834324e-01f}, {-7.071067812e-01f, 7.071067812e-01f}, {-3.826834324e-01f, 9.238795325e-01f}, {-1.836970199e-16f, 1.000000000e+00f}, {3.826834324e-01f, 9.238795325e-01f}, {7.071067812e-01f, 7.071067812e-01f}, {9.238795325e-01f, 3.826834324e-01f}};
+__device__ constexpr float kW32[32][2] = {{1.000000000e+00f, -0.000000000e+00f}, {9.807852804e-01f, -1.950903220e-01f}, {9.238795325e-01f, -3.826834324e-01f}, {8.314696123e-01f, -5.555702330e-01f}, {7.071067812e-01f, -7.071067812e-01f}, {5.555702330e-01f, -8.314696123e-01f}, {3.826834324e-01f, -9.238795325e-01f}, {1.950903220e-01f, -9.807852804e-01f}, {6.123233996e-17f, -1.000000000e+00f}, {-1.950903220e-01f, -9.807852804e-01f}, {-3.826834324e-01f, -9.238795325e-01f}, {-5.555702330e-01f, -8.314696123e-01f}, {-7.071067812e-01f, -7.071067812e-01f}, {-8.314696123e-01f, -5.555702330e-01f}, {-9.238795325e-01f, -3.826834324e-01f}, {-9.807852804e-01f, -1.950903220e-01f}, {-1.000000000e+00f, -1.224646799e-16f}, {-9.807852804e-01f, 1.950903220e-01f}, {-9.238795325e-01f, 3.826834324e-01f}, {-8.314696123e-01f, 5.555702330e-01f}, {-7.071067812e-01f, 7.071067812e-01f}, {-5.555702330e-01f, 8.314696123e-01f}, {-3.826834324e-01f, 9.238795325e-01f}, {-1.950903220e-01f, 9.807852804e-01f}, {-1.836970199e-16f, 1.000000000e+00f}, {1.950903220e-01f, 9.807852804e-01f}, {3.826834324e-01f, 9.238795325e-01f}, {5.555702330e-01f, 8.314696123e-01f}, {7.071067812e-01f, 7.071067812e-01f}, {8.314696123e-01f, 5.555702330e-01f}, {9.238795325e-01f, 3.826834324e-01f}, {9.807852804e-01f, 1.950903220e-01f}};
+template <int R> __device__ __forceinline__ float2 const_tw(int n) {
+    return R == 16 ? make_float2(kW16[n & 15][0], kW16[n & 15][1]) : make_float2(kW32[n & 31][0], kW32[n & 31][1]);
+}
+
+template <int T, bool DETREND, int MODE>
+__global__ __launch_bounds__(64 * kWaves) void stft_rbig_kernel(const BigParams p) {
+    constexpr int R = 8 * T, M = 64 * R, NB = M + 1;
+    constexpr int kSlab = T * 8 * kS1;                       // complex elements per wave
+    constexpr int kTw1 = M, kTw2 = kTw1 + (R - 1) * 64, kTw3 = kTw2 + 7 * 64, kTabs = kTw3 + (R / 2) * 64;
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float2* const buf = lds + kTabs + wave * kSlab;
+
+    for (int i = threadIdx.x; i < M; i += 64 * kWaves) lds[i] = p.win2[i];
+    for (int i = threadIdx.x; i < kTabs - M; i += 64 * kWaves) lds[M + i] = p.tw[i];
+    __syncthreads();
+
+    const int lw = xcd_remap(blockIdx.x, gridDim.x) * kWaves + wave;
+    if (lw >= p.n_waves) return;
+    int64_t g = p.total_frames * lw / p.n_waves;
+    const int64_t g_end = p.total_frames * (lw + 1) / p.n_waves;
+
+    const float2* const wtab = lds + lane;                   // + 64*a
+    const float2* const t1 = lds + kTw1 + lane;              // + 64*(r-1)
+    const float2* const t2 = lds + kTw2 + lane;              // + 64*(s-1)
+    const float2* const t3 = lds + kTw3 + lane;              // + 64*c
+    const int j0 = lane & 7, hi = lane >> 3;
+    float2* const x1w = buf + hi * kS1 + j0;                 // + q*8*kS1 + 8*r1
+    float2* const x1r = buf + lane;                          // + q*8*kS1 + b*kS1
+    float2* const x2w = buf + j0 * kS2 + hi;                 // + q3*8*kS2 + ((8q + R*s) % 64)
+    float2* const x2r = buf + lane;                          // + q3*8*kS2 + j0*kS2
+    float2* const x3w = buf + lane;                          // + 64*c
+    const float2* const x3b = buf + (M - lane);              // - 64*c
+
+    const float q_in = MODE == 0 ? p.scale * 0.5f : p.scale * 0.25f;
+    const float q0 = lane == 0 ? p.scale * 0.25f : q_in;
+
+    for (; g < g_end; ++g) {
+        const int clip = static_cast<int>(g / p.n_frames);
+        const int f = static_cast<int>(g - static_cast<int64_t>(clip) * p.n_frames);
+        const float* const src = p.x + static_cast<int64_t>(clip) * p.clip_stride + static_cast<int64_t>(f) * p.hop + 2 * lane;
+        float* const orow = p.out + static_cast<int64_t>(clip) * p.out_clip_stride + static_cast<int64_t>(f) * NB;
+
+        float2 d[T][8];
+#pragma unroll
+        for (int a0 = 0; a0 < T; ++a0)
+#pragma unroll
+            for (int a1 = 0; a1 < 8; ++a1) d[a0][a1] = *reinterpret_cast<const float2*>(src + 128 * (a0 + T * a1));
+
+        if (DETREND) {
+            float s = 0.f;
+#pragma unroll
+            for (int a0 = 0; a0 < T; ++a0)
+#pragma unroll
+                for (int a1 = 0; a1 < 8; ++a1) s += d[a0][a1].x + d[a0][a1].y;
+            const float mean = wave_sum(s) * (1.0f / (2 * M));
+#pragma unroll
+            for (int a0 = 0; a0 < T; ++a0)
+#pragma unroll
+                for (int a1 = 0; a1 < 8; ++a1) { d[a0][a1].x -= mean; d[a0][a1].y -= mean; }
+        }
+#pragma unroll
+        for (int a0 = 0; a0 < T; ++a0)
+#pragma unroll
+            for (int a1 = 0; a1 < 8; ++a1) {
+                const float2 w = lds_get(wtab + 64 * (a0 + T * a1));
+                d[a0][a1].x *= w.x; d[a0][a1].y *= w.y;
+            }
+
+        // ---- pass 1: R-point DFT over a = a0 + T*a1 --------------------------------------------------------
+#pragma unroll
+        for (int a0 = 0; a0 < T; ++a0) {
+            radix8(d[a0]);                                   // over a1 -> r1
+            if (a0 > 0) {
+#pragma unroll
+                for (int r1 = 1; r1 < 8; ++r1) d[a0][r1] = cmul(d[a0][r1], const_tw<R>(a0 * r1));
+            }
+        }
+#pragma unroll
+        for (int r1 = 0; r1 < 8; ++r1) {                     // over a0 -> r0 ; r = r1 + 8*r0
+            float2 v[T];
+#pragma unroll
+            for (int a0 = 0; a0 < T; ++a0) v[a0] = d[a0][r1];
+            radix_t<T>(v);
+#pragma unroll
+            for (int r0 = 0; r0 < T; ++r0) d[r0][r1] = v[r0];
+        }
+#pragma unroll
+        for (int q = 0; q < T; ++q)
+#pragma unroll
+            for (int r1 = 0; r1 < 8; ++r1)
+                if (q + r1 > 0) d[q][r1] = cmul(d[q][r1], lds_get(t1 + 64 * (r1 + 8 * q - 1)));
+#pragma unroll
+        for (int q = 0; q < T; ++q)
+#pragma unroll
+            for (int r1 = 0; r1 < 8; ++r1) lds_put(x1w + q * 8 * kS1 + 8 * r1, d[q][r1]);
+        wave_lds_fence();
+#pragma unroll
+        for (int q = 0; q < T; ++q)
+#pragma unroll
+            for (int b = 0; b < 8; ++b) d[q][b] = lds_get(x1r + q * 8 * kS1 + b * kS1);
+        wave_lds_fence();
+
+        // ---- pass 2 ----------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int q = 0; q < T; ++q) {
+            radix8(d[q]);
+#pragma unroll
+            for (int s = 1; s < 8; ++s) d[q][s] = cmul(d[q][s], lds_get(t2 + 64 * (s - 1)));
+        }
+#pragma unroll
+        for (int q = 0; q < T; ++q)
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int uu = 8 * q + R * s;                // + r1 (= hi) < 8 never carries into the next 64
+                lds_put(x2w + (uu / 64) * 8 * kS2 + (uu % 64), d[q][s]);
+            }
+        wave_lds_fence();
+#pragma unroll
+        for (int q3 = 0; q3 < T; ++q3)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[q3][j] = lds_get(x2r + q3 * 8 * kS2 + j * kS2);
+        wave_lds_fence();
+
+        // ---- pass 3: d[q3][t] = Z[lane + 64*(q3 + T*t)] ---------------------------------------------------
+#pragma unroll
+        for (int q3 = 0; q3 < T; ++q3) radix8(d[q3]);
+#pragma unroll
+        for (int q3 = 0; q3 < T; ++q3)
+#pragma unroll
+            for (int t = 4; t < 8; ++t) lds_put(x3w + 64 * (q3 + T * t), d[q3][t]);
+        if (lane == 0) lds_put(buf + M, d[0][0]);
+        wave_lds_fence();
+
+        // ---- split pass + epilogue --------------------------------------------------------------------------
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int q3 = 0; q3 < T; ++q3) {
+                const int c = q3 + T * t;
+                const float2 A = d[q3][t];
+                const float2 B = lds_get(x3b - 64 * c);
+                const float2 cs = lds_get(t3 + 64 * c);
+                const float2 S = make_float2(A.x + B.x, A.y - B.y);
+                const float2 D = make_float2(A.x - B.x, A.y + B.y);
+                const float2 Tt = make_float2(fmaf(cs.y, D.x, -cs.x * D.y), fmaf(cs.x, D.x, cs.y * D.y));
+                const float2 Xk = csub(S, Tt), Xm = cadd(S, Tt);
+                const float qq = c == 0 ? q0 : q_in;
+                float pk = fmaf(Xk.x, Xk.x, Xk.y * Xk.y) * qq;
+                float pm = fmaf(Xm.x, Xm.x, Xm.y * Xm.y) * qq;
+                if (MODE == 1) { pk = sqrtf(pk); pm = sqrtf(pm); }
+                const int k = lane + 64 * c;
+                orow[k] = pk;
+                orow[M - k] = pm;
+            }
+        {   // k = M/2: lane 0, register c = R/2 = d[0][4]
+            const float zx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d[0][4].x), 0));
+            const float zy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d[0][4].y), 0));
+            float pq = fmaf(zx, zx, zy * zy) * (q_in * 4.0f);
+            if (MODE == 1) pq = sqrtf(pq);
+            orow[M / 2] = pq;                                // wave-uniform store
+        }
+        wave_lds_fence();
+    }
+}
+
+template <int T, bool DETREND>
+int launch_td(const BigParams& prm, int n_wg, size_t lds, hipStream_t s, int mode) {
+    auto k0 = stft_rbig_kernel<T, DETREND, 0>;
+    auto k1 = stft_rbig_kernel<T, DETREND, 1>;
+    auto kern = mode == SG_MODE_PSD ? k0 : k1;
+    if (lds > 64 * 1024)
+        SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    hipLaunchKernelGGL(kern, dim3(n_wg), dim3(64 * kWaves), lds, s, prm);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SG_OK : hip_fail(e, "stft_rbig launch");
+}
+
+template <int T>
+int launch_t(const sg_plan& p, const StftArgs& a) {
+    constexpr int R = 8 * T, M = 64 * R;
+    BigParams prm{};
+    prm.x = static_cast<const float*>(a.x);
+    prm.clip_stride = a.clip_stride;
+    prm.n_frames = static_cast<int>(a.n_frames);
+    prm.hop = p.hop;
+    prm.total_frames = a.n_frames * a.n_clips;
+    const size_t lds = (static_cast<size_t>(M) + (R - 1 + 7 + R / 2) * 64 + static_cast<size_t>(kWaves) * T * 8 * kS1) * sizeof(float2);
+    const int wg_per_cu = static_cast<int>((160 * 1024) / lds) < 1 ? 1 : static_cast<int>((160 * 1024) / lds);
+    int64_t n_waves = static_cast<int64_t>(p.n_cu) * wg_per_cu * kWaves;
+    if (n_waves > prm.total_frames) n_waves = prm.total_frames;
+    prm.n_waves = static_cast<int>(n_waves);
+    prm.out = static_cast<float*>(a.out);
+    prm.out_clip_stride = a.out_clip_stride;
+    prm.win2 = static_cast<const float2*>(p.win_dev);
+    prm.tw = static_cast<const float2*>(p.r8_tw_dev);
+    prm.scale = static_cast<float>(p.scale);
+    const int n_wg = static_cast<int>((n_waves + kWaves - 1) / kWaves);
+    return p.detrend == SG_DETREND_CONSTANT ? launch_td<T, true>(prm, n_wg, lds, a.stream, p.mode)
+                                            : launch_td<T, false>(prm, n_wg, lds, a.stream, p.mode);
+}
+
+}  // namespace
+
+bool rbig_can_run(const sg_plan& p, const StftArgs& a) {
+    return !a.in_i16 && !a.band_mode && (p.hop % 2 == 0) && (a.clip_stride % 2 == 0 || a.n_clips == 1) &&
+           (reinterpret_cast<uintptr_t>(a.x) % 8 == 0) && a.n_frames <= INT32_MAX;
+}
+
+int launch_rbig(const sg_plan& p, const StftArgs& a) {
+    if (a.n_frames <= 0 || a.n_clips <= 0) return SG_OK;
+    return p.nfft == 2048 ? launch_t<2>(p, a) : launch_t<4>(p, a);
+}
+
+// Per-lane twiddle table [(R-1) + 7 + R/2][64] float2 (R = nfft/128), computed in double:
+//   t1[r-1][j] = exp(-2*pi*i*j*r/M), r = 1..R-1;  t2[s-1][j] = exp(-2*pi*i*(j&7)*s/64);  t3[c][j] = (cos, sin)(2*pi*(j+64c)/(2M))
+int build_rbig_tables(sg_plan& p) {
+    const int R = p.nfft / 128, M = 64 * R;
+    std::vector<float2> tw(static_cast<size_t>(R - 1 + 7 + R / 2) * 64);
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int j = 0; j < 64; ++j) {
+        for (int r = 1; r < R; ++r) {
+            const double ang = -two_pi * static_cast<double>((static_cast<long long>(j) * r) % M) / M;
+            tw[(r - 1) * 64 + j] = make_float2(static_cast<float>(std::cos(ang)), static_cast<float>(std::sin(ang)));
+        }
+        for (int s = 1; s < 8; ++s) {
+            const double ang = -two_pi * static_cast<double>(((j & 7) * s) % 64) / 64.0;
+            tw[(R - 1 + s - 1) * 64 + j] = make_float2(static_cast<float>(std::cos(ang)), static_cast<float>(std::sin(ang)));
+        }
+        for (int c = 0; c < R / 2; ++c) {
+            const double ang = two_pi * static_cast<double>(j + 64 * c) / (2.0 * M);
+            tw[(R - 1 + 7 + c) * 64 + j] = make_float2(static_cast<float>(std::cos(ang)), static_cast<float>(std::sin(ang)));
+        }
+    }
+    SG_HIP(hipMalloc(&p.r8_tw_dev, tw.size() * sizeof(float2)));
+    SG_HIP(hipMemcpy(p.r8_tw_dev, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
+    return SG_OK;
+}
+
+}  // namespace sg

@@ -274,3 +274,25 @@ def test_rsmall_kernel(sp, n, hop, detrend, mode):
     f2, t2, s2 = sp.spectrogram(y, fs=48000.0, nperseg=n, window="hann", noverlap=n - 33)
     _, _, so2 = orc.spectrogram(y, fs=48000.0, nperseg=n, window="hann", noverlap=n - 33)
     assert_spec_close(s2, so2, time_axis=-1)
+
+
+@pytest.mark.parametrize("n", [2048, 4096])
+@pytest.mark.parametrize("hop,detrend,mode", [(64, "constant", "psd"), (256, "constant", "psd"), (1024, False, "magnitude"),
+                                              (None, "constant", "psd")])
+def test_rbig_kernel(sp, n, hop, detrend, mode):
+    """Register kernel for nfft 2048 / 4096 (16 / 32 complex values per lane): vs oracle, several clips, ragged tail."""
+    from spectro import _capi
+    from spectro.signal import plan_for
+    from spectro.windows import get_window
+    hop = n - n // 8 if hop is None else hop
+    rng = np.random.default_rng(n + hop)
+    N = n + hop * 23 + 7
+    x = (rng.standard_normal((3, N)) * 0.4 + 0.2).astype(np.float32)
+    kw = dict(fs=48000.0, nperseg=n, window="hann", noverlap=n - hop, detrend=detrend, mode=mode)
+    f, t, s = sp.spectrogram(x, **kw)
+    fo, to, so = orc.spectrogram(x, **kw)
+    np.testing.assert_array_equal(f, fo)
+    np.testing.assert_array_equal(t, to)
+    assert_spec_close(s, so, time_axis=-1, bin_floor=1e-3 if mode == "psd" else 1e-3 ** 0.5)
+    plan = plan_for(get_window("hann", n), n, n, hop, _capi.DETREND[detrend], 48000.0, 0, _capi.MODE[mode], _capi.F32)
+    assert plan.kernel == "rbig"
