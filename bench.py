@@ -10,6 +10,10 @@ For N > 1 the driver launches one rank per GPU with torch.distributed.run; clips
 ranks with no data-path collective (weak scaling: every rank owns its own 64-clip batch); RCCL
 is used only for the barrier and the max-over-ranks time.  Rank 0 prints ONE JSON line.
 
+Defaults (500 timed steps after 100 warm-up steps, ~60 ms of GPU time) are long enough to get past the chip's
+power-management transient: the first ~12 launches run at 92 us, the next ~100 at up to 138 us, then the
+clock settles (profiles/r01d_kernel_trace_durations.txt); shorter runs measure the transient, not the kernel.
+
 PyTorch is plumbing here (device memory, streams, torch.distributed); the measured work is
 sg_stft from libspectro.so, called through the C ABI on torch's current stream.
 """
@@ -35,8 +39,8 @@ N_BUFFER_SETS = 4                               # rotate so the 256 MiB Infinity
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--clips", type=int, default=CLIPS_PER_GPU, help="clips per GPU (default: BASELINE cfg2 = 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline work")

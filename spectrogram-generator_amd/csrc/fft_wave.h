@@ -79,7 +79,14 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // LDS accesses go through volatile 64-bit vectors: hipcc otherwise fuses neighbouring ds_read_b64 /
 // ds_write_b64 into ds_read2_b64 / ds_write2_b64, which run at half the LDS rate on gfx950
 // (MI355X_MICROARCH.md LDS table: ds_read2_b64 128 B/clk vs ds_read_b64 256 B/clk).
+#ifndef SG_LDS_VOLATILE
+#define SG_LDS_VOLATILE 1
+#endif
+#if SG_LDS_VOLATILE
 typedef __attribute__((address_space(3))) volatile v2f lds_v2f;
+#else
+typedef __attribute__((address_space(3))) v2f lds_v2f;
+#endif
 __device__ __forceinline__ void lds_put(float2* p, float2 v) { *(lds_v2f*)(p) = v2f{v.x, v.y}; }
 __device__ __forceinline__ float2 lds_get(const float2* p) {
     const v2f v = *(lds_v2f*)(p);

@@ -38,7 +38,10 @@ constexpr int kS2 = 66;         // LDS stride of exchange 2: [j0][l3]
 constexpr int kSlab = 8 * kS1;  // 576 complex = 4608 B per wave
 constexpr int kWavesPerWg = 4;
 #ifndef SG_TW_LDS
-#define SG_TW_LDS 1              // 1: twiddles in a workgroup-shared LDS table (5 waves/SIMD); 0: in VGPRs (4 waves/SIMD)
+// 0: twiddles in VGPRs (4 waves/SIMD); 1: in a workgroup-shared LDS table (5 waves/SIMD).  Sustained A/B on MI355X
+// (bench.py, 400 steps): VGPR 96-97 us vs LDS 99.5 us per launch -- the 18 extra ds_read_b64 per frame cost more
+// (LDS time and power) than the fifth wave buys, so VGPR is the default.
+#define SG_TW_LDS 0
 #endif
 constexpr int kOccupancy = SG_TW_LDS ? 5 : 4;    // waves per SIMD the kernel is built for
 constexpr int kMinRun = 4;       // shortest run of frames worth a wave's prologue
@@ -87,18 +90,22 @@ struct R8Params {
 //
 // Work split: the grid is persistent (a few workgroups per CU); wave w owns a contiguous run of the flattened
 // (clip, frame) index space, runs differ by at most one frame, so there is no tail of half-empty rounds.
-// Twiddles live in a 9 KiB LDS table shared by the workgroup (keeps the kernel under 96 VGPRs = 5 waves/SIMD);
-// the window stays in VGPRs.
+// Window and twiddles stay in VGPRs (SG_TW_LDS=0, ~118 VGPRs = 4 waves/SIMD); SG_TW_LDS=1 moves the twiddles to a
+// 9 KiB workgroup-shared LDS table (83 VGPRs = 5 waves/SIMD).
 template <typename TIn, bool ALIGNED, bool DETREND, int MODE, bool BAND, int H>
 __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_kernel(const R8Params p) {
-    __shared__ __attribute__((aligned(16))) float2 lds[kWavesPerWg * kSlab + 18 * 64];
+    __shared__ __attribute__((aligned(16))) float2 lds[kWavesPerWg * kSlab + (SG_TW_LDS ? 18 * 64 : 0)];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float2* const buf = lds + wave * kSlab;
+#if SG_TW_LDS
     float2* const twl = lds + kWavesPerWg * kSlab;          // [18][64] twiddles, lane-linear rows
+#endif
 
+#if SG_TW_LDS
     for (int i = threadIdx.x; i < 18 * 64; i += 64 * kWavesPerWg) twl[i] = p.tw[i];
     __syncthreads();                                        // the only barrier: before any wave may exit
+#endif
 
 #ifdef SG_STAGGER
     {   // de-phase the workgroups that share a CU (experiment)
