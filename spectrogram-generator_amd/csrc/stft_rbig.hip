@@ -21,7 +21,10 @@ namespace {
 
 using namespace wavefft;
 
-constexpr int kS1 = 72, kS2 = 66, kWaves = 4;
+constexpr int kS1 = 72, kS2 = 66;
+// waves per workgroup: the LDS tables are shared by the workgroup, so T = 4 (43 KiB of tables, 18 KiB slab per wave)
+// packs 6 waves into its single workgroup per CU
+template <int T> struct WavesFor { static constexpr int value = T == 4 ? 6 : 4; };
 
 struct BigParams {
     const float* x;
@@ -57,8 +60,8 @@ template <int R> __device__ __forceinline__ float2 const_tw(int n) {
 }
 
 template <int T, bool DETREND, int MODE>
-__global__ __launch_bounds__(64 * kWaves) void stft_rbig_kernel(const BigParams p) {
-    constexpr int R = 8 * T, M = 64 * R, NB = M + 1;
+__global__ __launch_bounds__(64 * WavesFor<T>::value) void stft_rbig_kernel(const BigParams p) {
+    constexpr int R = 8 * T, M = 64 * R, NB = M + 1, kWaves = WavesFor<T>::value;
     constexpr int kSlab = T * 8 * kS1;                       // complex elements per wave
     constexpr int kTw1 = M, kTw2 = kTw1 + (R - 1) * 64, kTw3 = kTw2 + 7 * 64, kTabs = kTw3 + (R / 2) * 64;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
@@ -90,17 +93,36 @@ __global__ __launch_bounds__(64 * kWaves) void stft_rbig_kernel(const BigParams 
     const float q_in = MODE == 0 ? p.scale * 0.5f : p.scale * 0.25f;
     const float q0 = lane == 0 ? p.scale * 0.25f : q_in;
 
-    for (; g < g_end; ++g) {
-        const int clip = static_cast<int>(g / p.n_frames);
-        const int f = static_cast<int>(g - static_cast<int64_t>(clip) * p.n_frames);
+    // T = 2: the 16 float2 of frame g+1 are fetched before the FFT of frame g (register prefetch, +32 VGPRs);
+    // T = 4 has no registers to spare and loads at the top of the frame.
+    constexpr bool kPrefetch = T == 2;
+    auto load_frame = [&](int64_t gg, float2 (&dst)[T][8]) {
+        const int clip = static_cast<int>(gg / p.n_frames);
+        const int f = static_cast<int>(gg - static_cast<int64_t>(clip) * p.n_frames);
         const float* const src = p.x + static_cast<int64_t>(clip) * p.clip_stride + static_cast<int64_t>(f) * p.hop + 2 * lane;
-        float* const orow = p.out + static_cast<int64_t>(clip) * p.out_clip_stride + static_cast<int64_t>(f) * NB;
-
-        float2 d[T][8];
 #pragma unroll
         for (int a0 = 0; a0 < T; ++a0)
 #pragma unroll
-            for (int a1 = 0; a1 < 8; ++a1) d[a0][a1] = *reinterpret_cast<const float2*>(src + 128 * (a0 + T * a1));
+            for (int a1 = 0; a1 < 8; ++a1) dst[a0][a1] = *reinterpret_cast<const float2*>(src + 128 * (a0 + T * a1));
+    };
+    float2 nxt[kPrefetch ? T : 1][8];
+    if (kPrefetch && g < g_end) load_frame(g, reinterpret_cast<float2 (&)[T][8]>(nxt));
+
+    for (; g < g_end; ++g) {
+        const int clip = static_cast<int>(g / p.n_frames);
+        const int f = static_cast<int>(g - static_cast<int64_t>(clip) * p.n_frames);
+        float* const orow = p.out + static_cast<int64_t>(clip) * p.out_clip_stride + static_cast<int64_t>(f) * NB;
+
+        float2 d[T][8];
+        if (kPrefetch) {
+#pragma unroll
+            for (int a0 = 0; a0 < T; ++a0)
+#pragma unroll
+                for (int a1 = 0; a1 < 8; ++a1) d[a0][a1] = nxt[kPrefetch ? a0 : 0][a1];
+            if (g + 1 < g_end) load_frame(g + 1, reinterpret_cast<float2 (&)[T][8]>(nxt));
+        } else {
+            load_frame(g, d);
+        }
 
         if (DETREND) {
             float s = 0.f;
@@ -221,6 +243,7 @@ __global__ __launch_bounds__(64 * kWaves) void stft_rbig_kernel(const BigParams 
 
 template <int T, bool DETREND>
 int launch_td(const BigParams& prm, int n_wg, size_t lds, hipStream_t s, int mode) {
+    constexpr int kWaves = WavesFor<T>::value;
     auto k0 = stft_rbig_kernel<T, DETREND, 0>;
     auto k1 = stft_rbig_kernel<T, DETREND, 1>;
     auto kern = mode == SG_MODE_PSD ? k0 : k1;
@@ -233,7 +256,7 @@ int launch_td(const BigParams& prm, int n_wg, size_t lds, hipStream_t s, int mod
 
 template <int T>
 int launch_t(const sg_plan& p, const StftArgs& a) {
-    constexpr int R = 8 * T, M = 64 * R;
+    constexpr int R = 8 * T, M = 64 * R, kWaves = WavesFor<T>::value;
     BigParams prm{};
     prm.x = static_cast<const float*>(a.x);
     prm.clip_stride = a.clip_stride;

@@ -85,19 +85,30 @@ __global__ __launch_bounds__(64 * kWaves) void stft_rsmall_kernel(const SmallPar
     const float q_in = MODE == 0 ? p.scale * 0.5f : p.scale * 0.25f;
     const float q0 = lu == 0 ? p.scale * 0.25f : q_in;
 
-    for (; q < q_end; ++q) {
-        const int clip = static_cast<int>(q / p.groups_per_clip);
-        const int fg = static_cast<int>(q - static_cast<int64_t>(clip) * p.groups_per_clip) * G;
+    // loads of group q+1 are issued before the FFT of group q (one group of register prefetch)
+    auto load_group = [&](int64_t qq, float2 (&dst)[8]) {
+        const int clip = static_cast<int>(qq / p.groups_per_clip);
+        const int fg = static_cast<int>(qq - static_cast<int64_t>(clip) * p.groups_per_clip) * G;
         const float* const xclip = p.x + static_cast<int64_t>(clip) * p.clip_stride + 2 * lane;
-
-        float2 a[8];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int f = min(fg + g, p.n_frames - 1);                 // partial last group: recompute the last frame
             const float* const src = xclip + static_cast<int64_t>(f) * p.hop;
 #pragma unroll
-            for (int k = 0; k < R; ++k) a[g * R + k] = *reinterpret_cast<const float2*>(src + 128 * k);
+            for (int k = 0; k < R; ++k) dst[g * R + k] = *reinterpret_cast<const float2*>(src + 128 * k);
         }
+    };
+    float2 nxt[8];
+    if (q < q_end) load_group(q, nxt);
+
+    for (; q < q_end; ++q) {
+        const int clip = static_cast<int>(q / p.groups_per_clip);
+        const int fg = static_cast<int>(q - static_cast<int64_t>(clip) * p.groups_per_clip) * G;
+
+        float2 a[8];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) a[v] = nxt[v];
+        if (q + 1 < q_end) load_group(q + 1, nxt);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             if (DETREND) {
