@@ -74,11 +74,19 @@ def main():
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    # Rehearsal switch for a 1-GPU box: SPECTRO_BENCH_SAME_GPU=1 puts every rank on cuda:0 and uses gloo for the
+    # barrier / max-reduce (RCCL refuses two ranks on one device).  The driver's real runs use nccl, one GPU per rank.
+    same_gpu = os.environ.get("SPECTRO_BENCH_SAME_GPU") == "1"
+    if same_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if same_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from spectro import _capi
     from spectro.windows import get_window
@@ -123,7 +131,7 @@ def main():
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)                    # HIP events on the launch stream
 
-    t = torch.tensor([elapsed, dev_ms], device=dev, dtype=torch.float64)
+    t = torch.tensor([elapsed, dev_ms], device="cpu" if same_gpu else dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed_max, dev_ms_max = float(t[0]), float(t[1])

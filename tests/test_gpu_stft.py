@@ -296,3 +296,86 @@ def test_rbig_kernel(sp, n, hop, detrend, mode):
     assert_spec_close(s, so, time_axis=-1, bin_floor=1e-3 if mode == "psd" else 1e-3 ** 0.5)
     plan = plan_for(get_window("hann", n), n, n, hop, _capi.DETREND[detrend], 48000.0, 0, _capi.MODE[mode], _capi.F32)
     assert plan.kernel == "rbig"
+
+
+def test_random_shapes_property(sp):
+    """Property test over random (N, nperseg, hop, dtype, detrend): shapes, bit-exact f/t and frame indexing, values vs
+    the oracle.  Seeded (no hypothesis dependency on the GPU box); covers N < nperseg, odd and non power-of-two nperseg,
+    hop 1 .. nperseg, every kernel family."""
+    rng = np.random.default_rng(20260101)
+    families = set()
+    from spectro.signal import plan_for
+    from spectro.windows import get_window
+    from spectro import _capi
+    for it in range(60):
+        nper = int(rng.choice([8, 32, 33, 64, 96, 100, 128, 255, 256, 500, 512, 1000, 1024, 1536, 2048, 4096]))
+        hop = int(rng.integers(1, nper + 1)) if rng.random() < 0.7 else nper - nper // 8
+        hop = max(1, hop)
+        n_frames_target = int(rng.integers(1, 40))
+        N = nper + hop * (n_frames_target - 1) + int(rng.integers(0, hop))
+        if rng.random() < 0.15:
+            N = max(2, nper // 2)                                  # N < nperseg -> clamp + warning
+        dt = np.float64 if rng.random() < 0.25 else np.float32
+        detrend = rng.choice(["constant", "constant", False, "linear"])
+        detrend = False if detrend == "False" else detrend
+        window = rng.choice(["hann", "tukey", "boxcar"])
+        window = ("tukey", 0.25) if window == "tukey" else str(window)
+        x = (rng.standard_normal(N) * 0.5 + rng.uniform(-1, 1)).astype(dt)
+        kw = dict(fs=float(rng.choice([100.0, 500.0, 16000.0, 48000.0])), nperseg=nper, window=window, detrend=detrend)
+        if N >= nper:
+            kw["noverlap"] = nper - hop
+        with warnings.catch_warnings(record=True) as w1:
+            warnings.simplefilter("always")
+            f, t, s = sp.spectrogram(x, **kw)
+        with warnings.catch_warnings(record=True) as w2:
+            warnings.simplefilter("always")
+            fo, to, so = orc.spectrogram(x, **kw)
+        assert len([w for w in w1 if "nperseg" in str(w.message)]) == len([w for w in w2 if "nperseg" in str(w.message)])
+        np.testing.assert_array_equal(f, fo)
+        np.testing.assert_array_equal(t, to)
+        assert s.shape == so.shape and s.dtype == so.dtype, (it, kw, s.shape, so.shape)
+        if dt == np.float64:
+            tol = 1e-9 if detrend == "linear" else 1e-11
+            assert np.abs(s - so).max() <= tol * max(so.max(), 1e-300), (it, kw)
+        else:
+            fmax = so.max(axis=0, keepdims=True)
+            assert np.all(np.abs(s - so) <= 1e-4 * fmax + 1e-30), (it, kw, float(np.max(np.abs(s - so) / (fmax + 1e-30))))
+        n_eff = min(nper, N)
+        if N >= nper:
+            p = plan_for(get_window(window, n_eff), n_eff, n_eff, hop, _capi.DETREND[detrend], kw["fs"], 0, 0,
+                         _capi.F32 if dt == np.float32 else _capi.F64)
+            families.add(p.kernel)
+    assert {"r8x3", "rsmall", "rbig", "stockham", "bluestein"} <= families, families
+
+
+def test_abi_argument_errors(sp):
+    """C ABI error paths: bad sizes / strides / nulls return SG_ERR_ARG (-> ValueError), never launch."""
+    import ctypes as C
+    from spectro import _capi
+    from spectro.windows import get_window
+    lib = _capi.lib()
+    h = C.c_void_p()
+    w = np.ascontiguousarray(get_window("hann", 64))
+    wp = w.ctypes.data_as(C.POINTER(C.c_double))
+    for args in [(0, 64, 16), (64, 32, 16), (64, 64, 0), (64, 64, 65)]:
+        assert lib.sg_plan_create(C.byref(h), args[0], args[1], args[2], wp, 1, 1000.0, 0, 0, 0) == _capi.SG_ERR_ARG
+        assert _capi.last_error()
+    assert lib.sg_plan_create(C.byref(h), 64, 64, 16, wp, 7, 1000.0, 0, 0, 0) == _capi.SG_ERR_ARG
+    assert lib.sg_plan_create(C.byref(h), 64, 64, 16, wp, 1, -1.0, 0, 0, 0) == _capi.SG_ERR_ARG
+    assert lib.sg_plan_create(C.byref(h), 64, 64, 16, wp, 1, 1000.0, 0, 0, 5) == _capi.SG_ERR_ARG
+    plan = _capi.Plan(64, 64, 16, w, 1, 1000.0, 0, 0, _capi.F32)
+    buf = _capi.DeviceBuffer(4096 * 4)
+    out = _capi.DeviceBuffer(1 << 20)
+    with pytest.raises(ValueError):
+        plan.stft(buf.ptr, 1000, 500, 2, out.ptr, 1 << 16)          # clip_stride < n_samples
+    with pytest.raises(ValueError):
+        plan.stft(buf.ptr, 1000, 1000, 2, out.ptr, 10)              # out_clip_stride too small
+    with pytest.raises(ValueError):
+        plan.stft(None, 1000, 1000, 1, out.ptr, 1 << 16)            # null input
+    with pytest.raises(ValueError):
+        plan.band_power(buf.ptr, 1000, 1000, 1, 5, 99, out.ptr, 100)   # band outside the bins
+    plan.stft(buf.ptr, 10, 10, 1, out.ptr, 0)                      # fewer samples than nperseg: no frames, no launch
+    with pytest.raises(ValueError):
+        plan.force_kernel("nope")
+    with pytest.raises(NotImplementedError):
+        plan.force_kernel("r8x3")
