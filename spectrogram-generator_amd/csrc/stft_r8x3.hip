@@ -74,6 +74,7 @@ struct R8Params {
     int hop;
     int64_t total_frames;  // n_frames * n_clips, flattened index g = clip * n_frames + f
     int n_waves;           // waves in the grid; wave w owns g in [w*total/n_waves, (w+1)*total/n_waves)
+    int run_len;           // 0: one contiguous run per wave; R > 0: runs of R frames dealt round-robin (tuning aid)
     float* out;            // [clip][frame][513]   (MODE psd / magnitude) or [clip][frame] (BAND)
     int64_t out_clip_stride;
     const float2* win2;    // [512]  (w[2n], w[2n+1])
@@ -115,8 +116,8 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
 #endif
     const int lw = xcd_remap(blockIdx.x, gridDim.x) * kWavesPerWg + wave;     // logical wave index
     if (lw >= p.n_waves) return;
-    int64_t g = p.total_frames * lw / p.n_waves;
-    const int64_t g_end = p.total_frames * (lw + 1) / p.n_waves;
+    int64_t chunk = lw;
+    const int64_t n_chunks = p.run_len > 0 ? (p.total_frames + p.run_len - 1) / p.run_len : p.n_waves;
 
     float2 w[8];
 #pragma unroll
@@ -147,6 +148,9 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
     const float q_edge = p.scale * 0.25f;                                // bins 0 and 512
     const float q0 = lane == 0 ? q_edge : q_in;
 
+    for (; chunk < n_chunks; chunk += p.n_waves) {
+    int64_t g = p.run_len > 0 ? chunk * p.run_len : p.total_frames * lw / p.n_waves;
+    const int64_t g_end = p.run_len > 0 ? min(g + p.run_len, p.total_frames) : p.total_frames * (lw + 1) / p.n_waves;
     while (g < g_end) {                              // one iteration per clip touched by this run (1 or 2)
         const int clip = static_cast<int>(g / p.n_frames);
         const int f0 = static_cast<int>(g - static_cast<int64_t>(clip) * p.n_frames);
@@ -269,6 +273,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
             wave_lds_fence();    // next frame's exchange-1 writes stay behind these reads
         }
     }
+    }
 }
 
 template <typename TIn, bool ALIGNED, bool DETREND, int MODE, bool BAND, int H>
@@ -332,6 +337,8 @@ int launch_r8x3(const sg_plan& p, const StftArgs& a) {
     if (n_waves > by_work) n_waves = by_work;
     int64_t n_wg = (n_waves + kWavesPerWg - 1) / kWavesPerWg;
     prm.n_waves = static_cast<int>(n_waves);
+    prm.run_len = 0;
+    if (const char* e = getenv("SPECTRO_R8_RUN")) prm.run_len = atoi(e) > 0 ? atoi(e) : 0;   // tuning aid
     prm.out = static_cast<float*>(a.out);
     prm.out_clip_stride = a.out_clip_stride;
     prm.win2 = static_cast<const float2*>(p.win_dev);
