@@ -72,6 +72,10 @@ int sg_malloc(void** dev_ptr, size_t bytes);
 int sg_free(void* dev_ptr);
 int sg_host_alloc(void** host_ptr, size_t bytes); /* pinned */
 int sg_host_free(void* host_ptr);
+/* Pin an existing host range in place (hipHostRegister) so that copies from/to it run at PCIe speed and truly
+ * asynchronously; undo with sg_host_unregister.  Used by the shim for large numpy buffers. */
+int sg_host_register(void* host_ptr, size_t bytes);
+int sg_host_unregister(void* host_ptr);
 int sg_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream);
 int sg_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);
 int sg_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes, void* stream); /* ranges may not overlap */

@@ -180,6 +180,12 @@ int sg_host_alloc(void** host_ptr, size_t bytes) {
     return SG_OK;
 }
 int sg_host_free(void* host_ptr) { if (host_ptr) SG_HIP(hipHostFree(host_ptr)); return SG_OK; }
+int sg_host_register(void* host_ptr, size_t bytes) {
+    if (!host_ptr || !bytes) { set_error("null host range"); return SG_ERR_ARG; }
+    SG_HIP(hipHostRegister(host_ptr, bytes, hipHostRegisterDefault));
+    return SG_OK;
+}
+int sg_host_unregister(void* host_ptr) { if (host_ptr) SG_HIP(hipHostUnregister(host_ptr)); return SG_OK; }
 int sg_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream) {
     if (bytes) SG_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
     return SG_OK;

@@ -34,6 +34,8 @@ SIGNATURES = {
     "sg_free": (_i, [_vp]),
     "sg_host_alloc": (_i, [_pvp, _sz]),
     "sg_host_free": (_i, [_vp]),
+    "sg_host_register": (_i, [_vp, _sz]),
+    "sg_host_unregister": (_i, [_vp]),
     "sg_memcpy_h2d": (_i, [_vp, _vp, _sz, _vp]),
     "sg_memcpy_d2h": (_i, [_vp, _vp, _sz, _vp]),
     "sg_memcpy_d2d": (_i, [_vp, _vp, _sz, _vp]),
@@ -159,6 +161,27 @@ class DeviceBuffer:
         n = arr.nbytes if nbytes is None else nbytes
         check(lib().sg_memcpy_d2h(arr.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr), n, C.c_void_p(stream)))
         return arr
+
+
+class pinned:
+    """Context manager: pin numpy arrays in place for the duration of a transfer (no-op for small ones)."""
+
+    MIN_BYTES = 8 << 20
+
+    def __init__(self, *arrays):
+        self.arrays = [a for a in arrays if a is not None and a.nbytes >= self.MIN_BYTES]
+        self.done = []
+
+    def __enter__(self):
+        for a in self.arrays:
+            if lib().sg_host_register(C.c_void_p(a.ctypes.data), a.nbytes) == SG_OK:     # best effort: pageable copy still works
+                self.done.append(a)
+        return self
+
+    def __exit__(self, *exc):
+        for a in self.done:
+            lib().sg_host_unregister(C.c_void_p(a.ctypes.data))
+        return False
 
 
 def stream_sync(stream=None):

@@ -133,6 +133,8 @@ def spectrogram(x, fs=1.0, window=("tukey", .25), nperseg=None, noverlap=None, n
     d_in = _capi.DeviceBuffer(xh.nbytes)
     d_out = _capi.DeviceBuffer(max(out.nbytes, 8))
     try:
+        # (pinning the numpy buffers in place with sg_host_register was measured: 18-27 ms vs 23 ms for the cfg2
+        #  batch -- registration costs what it saves; callers that care keep data on the device via spectro.engine)
         d_in.upload(xh)
         plan.stft(d_in.ptr, n_samples, n_samples, n_clips, d_out.ptr, n_frames * n_bins * per_bin, int16=use_i16)
         d_out.download(out)
