@@ -188,6 +188,16 @@ int sg_mel_pack_weights(const double* weights_host, int n_bins, int n_mels, floa
 int sg_mel(const float* spec_dev, int64_t n_frames, int n_bins, const float* weights_dev, int n_mels,
            const int* tile_k_lo, const int* tile_k_hi, int log_scale, float* mel_dev, void* stream);
 
+/*
+ * BASELINE cfg3 fused: framing .. PSD as in sg_stft, then the mel contraction as an MFMA epilogue inside the same
+ * kernel; only mel_dev[n_clips][n_frames][n_mels] is written (hop*4 + n_mels*4 algorithmic bytes per frame).
+ * Needs an f32 nperseg = nfft = 1024 PSD plan (sg_plan_kernel == "r8x3"), an even hop and 8-byte aligned float input;
+ * SG_ERR_UNSUPPORTED otherwise (use sg_stft + sg_mel).  Weights/ranges as for sg_mel.  Asynchronous.
+ */
+int sg_stft_mel(const sg_plan* plan, const float* x_dev, int64_t n_samples, int64_t clip_stride, int n_clips,
+                const float* packed_weights_dev, int n_mels, const int* tile_k_lo, const int* tile_k_hi,
+                int log_scale, float* mel_dev, int64_t out_clip_stride, void* stream);
+
 /* ---- timing helper used by bench.py (HIP events on `stream`) ---------- */
 /* Runs sg_stft `iters` times back to back between two hipEvents and returns the
  * average milliseconds per launch.  Synchronises `stream`. */

@@ -18,14 +18,14 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libspectro.so")
-SOURCES = ["spectro_api.hip", "stft_r8x3.hip", "stft_rsmall.hip", "stft_rbig.hip", "stft_stockham.hip", "stft_bluestein.hip", "epilogue.hip", "mel.hip"]
+SOURCES = ["spectro_api.hip", "stft_r8x3.hip", "stft_rsmall.hip", "stft_rbig.hip", "stft_stockham.hip", "stft_bluestein.hip", "epilogue.hip", "mel.hip", "stft_mel_fused.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-fno-gpu-rdc",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 # Per-file extras.  stft_r8x3 is VALU-bound: gfx950 issues v_pk_*_f32 at half the rate of the plain ops
 # (tools/ubench/valu_rate.hip: 2.2 ns vs 1.2 ns per wave-instruction per SIMD), so SLP packing only adds
 # register-pair shuffles (v_pk_mov/v_mov) -- keep the scalar forms.
 EXTRA = {"stft_r8x3.hip": (["-fno-slp-vectorize"] if not os.environ.get("SG_SLP") else []) + os.environ.get("SG_R8_DEFS", "").split(),
-         "stft_rsmall.hip": ["-fno-slp-vectorize"], "stft_rbig.hip": ["-fno-slp-vectorize"]}
+         "stft_rsmall.hip": ["-fno-slp-vectorize"], "stft_rbig.hip": ["-fno-slp-vectorize"], "stft_mel_fused.hip": ["-fno-slp-vectorize"]}
 
 
 def hipcc():

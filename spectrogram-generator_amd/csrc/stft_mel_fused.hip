@@ -1,0 +1,272 @@
+// stft_mel_fused.hip -- BASELINE cfg3: STFT (nperseg = nfft = 1024, f32, PSD) with the mel filterbank fused as an
+// MFMA epilogue; the linear spectrum never reaches HBM.  Algorithmic bytes per frame: hop*4 in + n_mels*4 out
+// (1344 B at hop 256 / 80 bands, against 3076 + 2052 + 320 B for sg_stft followed by sg_mel).
+//
+// A 256-thread workgroup owns a tile of 16 consecutive frames of one clip:
+//   phase 1  each of the 4 wavefronts runs the r8x3 pipeline (stft_r8x3.hip: register radix-8 x3, padded LDS
+//            transposes, split pass) on 4 consecutive frames and writes |X|^2*scale rows into a shared LDS tile
+//            [16][520] instead of global memory;
+//   phase 2  the tile is the A operand of v_mfma_f32_16x16x4_f32 (exact f32): wave w takes the 16-bin k blocks
+//            w, w+4, ... and, for every 16-band mel tile whose triangles cover the block, one float4 of the packed
+//            transposed weights (sg_mel_pack_weights) as B; partial accumulators are summed across the 4 waves
+//            through LDS and stored as [frame][mel] rows (optionally 10*log10).
+// The mel definition is this library's own (the reference has no mel stage; parity unpinned).
+#include "spectro_internal.h"
+#include "fft_wave.h"
+
+#include <cmath>
+#include <cstdlib>
+
+namespace sg {
+namespace {
+
+using namespace wavefft;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kM = 512, kN = 1024;
+constexpr int kS1 = 72, kS2 = 66, kSlab = 8 * kS1;
+constexpr int kRow = 520;                 // floats per tile row: 513 bins + zero pad, 16-byte aligned rows
+constexpr int kTileFloats = 16 * kRow + 16;
+constexpr int kMaxTiles = 8;
+
+struct FusedParams {
+    const float* x;
+    int64_t clip_stride;
+    int n_frames, hop;
+    int tiles_per_clip;
+    int64_t total_tiles;
+    int n_wgs;
+    float* out;                // [clip][frame][n_mels]
+    int64_t out_clip_stride;
+    const float2* win2;
+    const float2* tw;          // r8x3 per-lane twiddles [18][64]
+    float scale;
+    const float* wt;           // packed mel weights [16*NT][k_pad]
+    int k_pad, n_mels, log_scale;
+    int k_lo[kMaxTiles], k_hi[kMaxTiles];
+};
+
+// H = hop/128 for hop 256 (register sliding window like stft_r8x3), 0 otherwise.
+template <bool DETREND, int NT, int H>
+__global__ __launch_bounds__(256) void stft1024_mel_kernel(const FusedParams p) {
+    __shared__ __attribute__((aligned(16))) float2 slabs[4 * kSlab];
+    __shared__ __attribute__((aligned(16))) float tile[kTileFloats];       // phase 2 partial sums alias the front of it
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float2* const buf = slabs + wave * kSlab;
+
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    if (wg >= p.n_wgs) return;
+    int64_t tid_tile = p.total_tiles * wg / p.n_wgs;
+    const int64_t tile_end = p.total_tiles * (wg + 1) / p.n_wgs;
+
+    float2 w[8], t1[7], t2[7], t3[4];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) w[a] = p.win2[lane + 64 * a];
+#pragma unroll
+    for (int r = 0; r < 7; ++r) { t1[r] = p.tw[r * 64 + lane]; t2[r] = p.tw[(7 + r) * 64 + lane]; }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) t3[m] = p.tw[(14 + m) * 64 + lane];
+
+    const int j0 = lane & 7, hi = lane >> 3;
+    float2* const x1w = buf + hi * kS1 + j0;
+    float2* const x1r = buf + lane;
+    float2* const x2w = buf + j0 * kS2 + hi;
+    float2* const x2r = buf + lane;
+    float2* const x3w = buf + lane;
+    const float2* const x3b = buf + (kM - lane);
+    const float q_in = p.scale * 0.5f, q0 = lane == 0 ? p.scale * 0.25f : q_in;
+    const int mi = lane & 15, kq = lane >> 4;
+
+    for (; tid_tile < tile_end; ++tid_tile) {
+        const int clip = static_cast<int>(tid_tile / p.tiles_per_clip);
+        const int ft0 = static_cast<int>(tid_tile - static_cast<int64_t>(clip) * p.tiles_per_clip) * 16;
+        const int my_f0 = ft0 + 4 * wave;
+        const int n_my = max(0, min(4, p.n_frames - my_f0));
+        const float* const xclip = p.x + static_cast<int64_t>(clip) * p.clip_stride + 2 * lane;
+
+        // zero the pad columns of this wave's rows (bins 513..519) and, once, the 16 floats behind the last row:
+        // phase 2 reads k up to k_pad-1 = 527 and the padded weights there are zero, but 0 * garbage must stay finite
+        if (lane < 28) tile[(4 * wave + lane / 7) * kRow + 513 + lane % 7] = 0.f;
+        if (wave == 3 && lane < 16) tile[16 * kRow + lane] = 0.f;
+
+        // ---------------- phase 1: 4 frames per wave through the r8x3 pipeline ----------------
+        float2 raw[8];
+        if (n_my > 0) {
+            const float* const src0 = xclip + static_cast<int64_t>(my_f0) * p.hop;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) raw[k] = *reinterpret_cast<const float2*>(src0 + 128 * k);
+        }
+        for (int i = 0; i < 4; ++i) {
+            float* const trow = tile + (4 * wave + i) * kRow;
+            if (i >= n_my) {                         // frames past the end of the clip: a finite dummy row
+#pragma unroll
+                for (int m = 0; m < 4; ++m) { trow[lane + 64 * m] = 0.f; trow[kM - lane - 64 * m] = 0.f; }
+                trow[256] = 0.f;
+                continue;
+            }
+            float2 a[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] = raw[k];
+            if (i + 1 < n_my) {                      // prefetch the next frame before this frame's FFT
+                const float* const nxt = xclip + static_cast<int64_t>(my_f0 + i + 1) * p.hop;
+                if (H > 0) {
+#pragma unroll
+                    for (int k = 0; k + H < 8; ++k) raw[k] = raw[k + H];
+#pragma unroll
+                    for (int k = (H > 0 ? 8 - H : 0); k < 8; ++k) raw[k] = *reinterpret_cast<const float2*>(nxt + 128 * k);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) raw[k] = *reinterpret_cast<const float2*>(nxt + 128 * k);
+                }
+            }
+            if (DETREND) {
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s += a[k].x + a[k].y;
+                const float mean = wave_sum(s) * (1.0f / kN);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { a[k].x -= mean; a[k].y -= mean; }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { a[k].x *= w[k].x; a[k].y *= w[k].y; }
+            radix8(a);
+#pragma unroll
+            for (int r = 1; r < 8; ++r) a[r] = cmul(a[r], t1[r - 1]);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) lds_put(x1w + 8 * r, a[r]);
+            wave_lds_fence();
+#pragma unroll
+            for (int b = 0; b < 8; ++b) a[b] = lds_get(x1r + b * kS1);
+            wave_lds_fence();
+            radix8(a);
+#pragma unroll
+            for (int s = 1; s < 8; ++s) a[s] = cmul(a[s], t2[s - 1]);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) lds_put(x2w + 8 * s, a[s]);
+            wave_lds_fence();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = lds_get(x2r + j * kS2);
+            wave_lds_fence();
+            radix8(a);
+#pragma unroll
+            for (int t = 4; t < 8; ++t) lds_put(x3w + 64 * t, a[t]);
+            if (lane == 0) lds_put(buf + kM, a[0]);
+            wave_lds_fence();
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float2 A = a[m];
+                const float2 B = lds_get(x3b - 64 * m);
+                const float2 cs = t3[m];
+                const float2 S = make_float2(A.x + B.x, A.y - B.y);
+                const float2 D = make_float2(A.x - B.x, A.y + B.y);
+                const float2 T = make_float2(fmaf(cs.y, D.x, -cs.x * D.y), fmaf(cs.x, D.x, cs.y * D.y));
+                const float2 Xk = csub(S, T), Xm = cadd(S, T);
+                const float q = m == 0 ? q0 : q_in;
+                trow[lane + 64 * m] = fmaf(Xk.x, Xk.x, Xk.y * Xk.y) * q;
+                trow[kM - lane - 64 * m] = fmaf(Xm.x, Xm.x, Xm.y * Xm.y) * q;
+            }
+            if (lane == 0) trow[256] = fmaf(a[4].x, a[4].x, a[4].y * a[4].y) * (q_in * 4.0f);
+            wave_lds_fence();
+        }
+        __syncthreads();                                              // tile complete
+
+        // ---------------- phase 2: mel contraction on the matrix cores ----------------
+        f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* const wrow = p.wt + static_cast<int64_t>(mi) * p.k_pad + 4 * kq;
+        for (int k0 = 16 * wave; k0 < p.k_pad; k0 += 64) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(tile + mi * kRow + k0 + 4 * kq);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (k0 >= p.k_lo[t] && k0 < p.k_hi[t]) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(wrow + static_cast<int64_t>(16 * t) * p.k_pad + k0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[1], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[2], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], acc[t], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                                              // every wave is done reading the tile
+        f32x4* const part = reinterpret_cast<f32x4*>(tile);           // [wave][t][lane] f32x4
+#pragma unroll
+        for (int t = 0; t < NT; ++t) part[(wave * NT + t) * 64 + lane] = acc[t];
+        __syncthreads();
+        // reduce the 4 partials; accumulator map: col = l&15 (mel), row = 4*(l>>4) + reg (frame)
+        for (int o = threadIdx.x; o < 16 * 16 * NT; o += 256) {
+            const int row = o / (16 * NT), col = o - row * (16 * NT);
+            const int t = col >> 4, l = (col & 15) + 16 * (row >> 2), r = row & 3;
+            float v = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) v += tile[((ww * NT + t) * 64 + l) * 4 + r];
+            const int f = ft0 + row;
+            if (col < p.n_mels && f < p.n_frames) {
+                if (p.log_scale) v = 10.0f * log10f(fmaxf(v, 1e-10f));
+                p.out[static_cast<int64_t>(clip) * p.out_clip_stride + static_cast<int64_t>(f) * p.n_mels + col] = v;
+            }
+        }
+        __syncthreads();                                              // the next tile overwrites the aliased region
+    }
+}
+
+template <bool DETREND, int H>
+int launch_nt(const FusedParams& prm, int nt, int n_wg, hipStream_t s) {
+#define SG_FUSED_CASE(N) case N: hipLaunchKernelGGL((stft1024_mel_kernel<DETREND, N, H>), dim3(n_wg), dim3(256), 0, s, prm); break;
+    switch (nt) {
+        SG_FUSED_CASE(1) SG_FUSED_CASE(2) SG_FUSED_CASE(3) SG_FUSED_CASE(4)
+        SG_FUSED_CASE(5) SG_FUSED_CASE(6) SG_FUSED_CASE(7) default: SG_FUSED_CASE(8)
+    }
+#undef SG_FUSED_CASE
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SG_OK : hip_fail(e, "stft1024_mel launch");
+}
+
+}  // namespace
+}  // namespace sg
+
+using namespace sg;
+
+extern "C" int sg_stft_mel(const sg_plan* plan, const float* x_dev, int64_t n_samples, int64_t clip_stride, int n_clips,
+                           const float* packed_weights_dev, int n_mels, const int* tile_k_lo, const int* tile_k_hi,
+                           int log_scale, float* mel_dev, int64_t out_clip_stride, void* stream) {
+    if (!plan || !x_dev || !packed_weights_dev || !mel_dev) { set_error("null pointer"); return SG_ERR_ARG; }
+    if (plan->kernel != Kernel::R8X3 || plan->mode != SG_MODE_PSD) {
+        set_error("fused STFT+mel needs an f32 nperseg = nfft = 1024 PSD plan (kernel r8x3)");
+        return SG_ERR_UNSUPPORTED;
+    }
+    if (n_mels < 1 || n_mels > 16 * kMaxTiles || n_clips < 0 || n_samples < 0) { set_error("bad sizes"); return SG_ERR_ARG; }
+    if ((plan->hop & 1) || (clip_stride & 1) || (reinterpret_cast<uintptr_t>(x_dev) & 7)) {
+        set_error("fused STFT+mel needs an even hop / clip stride and 8-byte aligned input");
+        return SG_ERR_UNSUPPORTED;
+    }
+    const int64_t n_frames = n_samples < plan->nperseg ? 0 : (n_samples - plan->nperseg) / plan->hop + 1;
+    if (n_frames == 0 || n_clips == 0) return SG_OK;
+    if (n_clips > 1 && (clip_stride < n_samples || out_clip_stride < n_frames * n_mels)) { set_error("bad strides"); return SG_ERR_ARG; }
+    FusedParams prm{};
+    prm.x = x_dev; prm.clip_stride = clip_stride; prm.n_frames = static_cast<int>(n_frames); prm.hop = plan->hop;
+    prm.tiles_per_clip = static_cast<int>((n_frames + 15) / 16);
+    prm.total_tiles = static_cast<int64_t>(prm.tiles_per_clip) * n_clips;
+    int64_t n_wgs = static_cast<int64_t>(plan->n_cu) * 3;
+    if (n_wgs > prm.total_tiles) n_wgs = prm.total_tiles;
+    prm.n_wgs = static_cast<int>(n_wgs);
+    prm.out = mel_dev; prm.out_clip_stride = out_clip_stride;
+    prm.win2 = static_cast<const float2*>(plan->win_dev);
+    prm.tw = static_cast<const float2*>(plan->r8_tw_dev);
+    prm.scale = static_cast<float>(plan->scale);
+    prm.wt = packed_weights_dev;
+    prm.k_pad = (plan->nfft / 2 + 1 + 15) & ~15;
+    prm.n_mels = n_mels; prm.log_scale = log_scale;
+    const int nt = (n_mels + 15) / 16;
+    for (int t = 0; t < nt; ++t) {
+        prm.k_lo[t] = tile_k_lo ? tile_k_lo[t] & ~15 : 0;
+        prm.k_hi[t] = tile_k_hi ? (tile_k_hi[t] + 15) & ~15 : prm.k_pad;
+        if (prm.k_lo[t] < 0) prm.k_lo[t] = 0;
+        if (prm.k_hi[t] > prm.k_pad) prm.k_hi[t] = prm.k_pad;
+    }
+    auto s = static_cast<hipStream_t>(stream);
+    const bool det = plan->detrend == SG_DETREND_CONSTANT;
+    if (plan->hop == 256) return det ? launch_nt<true, 2>(prm, nt, prm.n_wgs, s) : launch_nt<false, 2>(prm, nt, prm.n_wgs, s);
+    return det ? launch_nt<true, 0>(prm, nt, prm.n_wgs, s) : launch_nt<false, 0>(prm, nt, prm.n_wgs, s);
+}

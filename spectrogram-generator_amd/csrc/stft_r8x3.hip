@@ -108,12 +108,6 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
     __syncthreads();                                        // the only barrier: before any wave may exit
 #endif
 
-#ifdef SG_STAGGER
-    {   // de-phase the workgroups that share a CU (experiment)
-        const int phase = blockIdx.x / 256;
-        for (int i = 0; i < phase * SG_STAGGER; ++i) __builtin_amdgcn_s_sleep(16);
-    }
-#endif
     const int lw = xcd_remap(blockIdx.x, gridDim.x) * kWavesPerWg + wave;     // logical wave index
     if (lw >= p.n_waves) return;
     int64_t chunk = lw;

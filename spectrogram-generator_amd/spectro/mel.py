@@ -63,5 +63,28 @@ class MelBank:
                 d.free()
         return np.moveaxis(out.reshape(*dev_spec.outer, dev_spec.n_frames, self.n_mels), -1, -2)
 
+    def stft_mel(self, x, plan, log_scale: bool = False):
+        """Fused STFT -> mel (sg_stft_mel): ``x`` is ``[n_clips, n_samples]`` float32 on the host, ``plan`` an r8x3 PSD plan.
+        Returns ``[n_clips, n_mels, n_frames]``; the linear spectrum is never materialised."""
+        x = np.ascontiguousarray(np.atleast_2d(x), np.float32)
+        n_clips, n_samples = x.shape
+        n_frames = plan.n_frames(n_samples)
+        out = np.empty((n_clips, n_frames, self.n_mels), np.float32)
+        d_in, d_out = _capi.DeviceBuffer(max(x.nbytes, 8)), _capi.DeviceBuffer(max(out.nbytes, 8))
+        try:
+            d_in.upload(x)
+            self.stft_mel_ptr(plan, d_in.ptr, n_samples, n_samples, n_clips, d_out.ptr, n_frames * self.n_mels, log_scale)
+            d_out.download(out)
+            _capi.stream_sync()
+        finally:
+            d_in.free()
+            d_out.free()
+        return np.moveaxis(out, 1, 2)
+
+    def stft_mel_ptr(self, plan, x_ptr, n_samples, clip_stride, n_clips, out_ptr, out_clip_stride, log_scale=False, stream=None):
+        _capi.check(_capi.lib().sg_stft_mel(plan.handle, C.c_void_p(x_ptr), int(n_samples), int(clip_stride), int(n_clips),
+                                            C.c_void_p(self._dev.ptr), self.n_mels, self._k_lo, self._k_hi,
+                                            int(bool(log_scale)), C.c_void_p(out_ptr), int(out_clip_stride), C.c_void_p(stream)))
+
     def close(self):
         self._dev.free()

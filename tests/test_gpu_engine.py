@@ -197,3 +197,38 @@ def test_streaming_equals_offline(nperseg, hop, n_ch, fs):
     assert_spec_close(s_all, s_ref, time_axis=-1)             # same samples; the kernel variant may differ (alignment)
     assert np.abs(s_all - s_ref).max() <= 2e-6 * s_ref.max()
     st.close()
+
+
+@pytest.mark.parametrize("hop,n_mels,detrend", [(256, 80, "constant"), (896, 40, "constant"), (130, 128, False)])
+def test_fused_stft_mel(hop, n_mels, detrend):
+    """cfg3 fused kernel (sg_stft_mel): equals mel(oracle PSD) and the unfused sg_stft + sg_mel path, incl. a frame
+    count that is not a multiple of the 16-frame tile and several clips."""
+    from oracle import mel_oracle
+    from spectro import _capi, engine
+    from spectro.mel import MelBank
+    from spectro.signal import plan_for
+    from spectro.windows import get_window
+    rng = np.random.default_rng(hop)
+    N = 1024 + hop * 53 + 11
+    x = (rng.standard_normal((3, N)) * np.linspace(0.1, 1.0, N) + 0.3).astype(np.float32)
+    if N % 2:
+        x = np.ascontiguousarray(x[:, :-1])
+    bank = MelBank(1024, 48000.0, n_mels, 30.0, 22000.0)
+    plan = plan_for(get_window("hann", 1024), 1024, 1024, hop, _capi.DETREND[detrend], 48000.0, 0, 0, _capi.F32)
+    assert plan.kernel == "r8x3"
+    _, _, s = orc.spectrogram(x, fs=48000.0, nperseg=1024, window="hann", noverlap=1024 - hop, detrend=detrend)
+    w32 = bank.weights.astype(np.float32)
+    for log in (False, True):
+        got = bank.stft_mel(x, plan, log_scale=log)
+        ref = np.moveaxis(mel_oracle.mel_spectrogram(np.moveaxis(s, -1, -2), w32, log), -1, -2)
+        assert got.shape == ref.shape == (3, n_mels, s.shape[-1])
+        if log:
+            assert np.abs(got - ref).max() < 2e-3
+        else:
+            assert np.abs(got - ref).max() <= 1e-4 * ref.max(axis=1, keepdims=True).max()
+            assert np.allclose(got, ref, rtol=1e-4, atol=1e-5 * ref.max())
+    dev = engine.stft(x, fs=48000.0, nperseg=1024, window="hann", noverlap=1024 - hop, detrend=detrend)
+    unfused = bank.apply(dev)
+    fused = bank.stft_mel(x, plan)
+    assert np.allclose(fused, unfused, rtol=2e-5, atol=1e-6 * unfused.max())
+    dev.free(); bank.close()

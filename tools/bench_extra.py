@@ -46,11 +46,15 @@ frames = n_clips * nfr
 t_stft = timed(lambda: plan.stft(d_in.ptr, N, N, n_clips, d_spec.ptr, nfr * 513))
 t_mel = timed(lambda: bank.apply_ptr(d_spec.ptr, frames, d_mel.ptr, True))
 t_mel_dense = timed(lambda: bank.apply_ptr(d_spec.ptr, frames, d_mel.ptr, True, dense=True))
+t_fused = timed(lambda: bank.stft_mel_ptr(plan, d_in.ptr, N, N, n_clips, d_mel.ptr, nfr * 80, True))
 steps_sparse = sum((hi - lo) // 4 for lo, hi in bank.tile_ranges)
 flops_dense = 2.0 * 513 * 80 * frames
 res["cfg3_mel"] = {
     "frames": frames, "stft_us": t_stft * 1e6, "mel_us": t_mel * 1e6, "mel_dense_us": t_mel_dense * 1e6,
     "stft_plus_mel_frames_per_s": frames / (t_stft + t_mel),
+    "fused_us": t_fused * 1e6, "fused_frames_per_s": frames / t_fused,
+    "fused_algorithmic_GBps": frames * (256 + 80) * 4 / t_fused / 1e9,
+    "fused_mfma_issued_TFLOPs": frames / 16 * steps_sparse * 2 * 16 * 16 * 4 / t_fused / 1e12,
     "mel_hbm_GBps": frames * (513 + 80) * 4 / t_mel / 1e9,
     "mfma_issued_TFLOPs_sparse": frames / 16 * steps_sparse * 2 * 16 * 16 * 4 / t_mel / 1e12,
     "mfma_issued_TFLOPs_dense": frames / 16 * 5 * 129 * 2 * 16 * 16 * 4 / t_mel_dense / 1e12,
