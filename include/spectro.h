@@ -167,6 +167,13 @@ int sg_band_totals(const void* spec_dev, int dtype, int64_t n_frames, int n_bins
 int sg_slice_bins(const void* spec_dev, int dtype, int64_t n_frames, int n_bins, int k_lo, int k_hi,
                   void* dst_dev, void* stream);
 
+/* ---- display epilogue: normalised image -> RGBA (replaces the colour mapping matplotlib's pcolormesh(cmap='jet',
+ *      vmin=0, vmax=1) does on the host at PlotEngine.py:134-135) ------------------------------------------------ */
+/* 256-entry 'jet' table as matplotlib builds it (segment data sampled at i/255), rgba_host[256][4] in 0..255. */
+int sg_jet_lut(uint8_t* rgba_host);
+/* rgba_dev[i] = lut_dev[clamp(int(img[i]*256), 0, 255)] (NaN -> transparent black), img f32 in [0,1]; n elements. */
+int sg_colormap(const float* img_dev, int64_t n, const uint8_t* lut_dev /* [256][4] */, uint8_t* rgba_dev, void* stream);
+
 /* ---- mel filterbank (BASELINE cfg3; NOT in the reference: definition is this library's own) ---- */
 /*
  * HTK mel scale m = 2595*log10(1 + f/700), n_mels triangular filters with peak 1 (no area normalisation)

@@ -61,6 +61,8 @@ SIGNATURES = {
     "sg_band_sum": (_i, [_vp, _i, _i64, _i, _i, _i, _vp, _vp]),
     "sg_band_totals": (_i, [_vp, _i, _i64, _i, _i, C.POINTER(_i), C.POINTER(_i), _vp, _vp]),
     "sg_slice_bins": (_i, [_vp, _i, _i64, _i, _i, _i, _vp, _vp]),
+    "sg_jet_lut": (_i, [C.POINTER(C.c_uint8)]),
+    "sg_colormap": (_i, [_vp, _i64, _vp, _vp, _vp]),
     "sg_mel_weights": (_i, [_i, _d, _i, _d, _d, C.POINTER(_d)]),
     "sg_mel_pack_weights": (_i, [C.POINTER(_d), _i, _i, C.POINTER(C.c_float)]),
     "sg_mel_tile_ranges": (_i, [C.POINTER(_d), _i, _i, C.POINTER(_i), C.POINTER(_i)]),

@@ -104,6 +104,32 @@ class DeviceSpectrogram:
                 d.free()
         return np.moveaxis(out.reshape(*self.outer, self.n_frames, width), -1, -2)
 
+    def image_rgba(self, k_lo, k_hi, log_scale, global_max=None):
+        """A9/A10 + colour mapping on the device: the RGBA bytes matplotlib's ``pcolormesh(cmap='jet', vmin=0, vmax=1)``
+        would compute from ``image()`` (PlotEngine.py:134-135) -> uint8 ``[n_mask, n_frames, 4]`` ready for ``imshow``."""
+        if self.dtype_code != _capi.F32:
+            raise ValueError("image_rgba needs an f32 spectrum")
+        width = k_hi - k_lo + 1
+        n = self.rows * width
+        out = np.empty((self.n_clips, self.n_frames, width, 4), np.uint8)
+        if n:
+            lut = np.empty((256, 4), np.uint8)
+            _capi.check(_capi.lib().sg_jet_lut(lut.ctypes.data_as(C.POINTER(C.c_uint8))))
+            d_img, d_lut, d_rgba = _capi.DeviceBuffer(n * 4), _capi.DeviceBuffer(1024), _capi.DeviceBuffer(n * 4)
+            try:
+                d_lut.upload(lut)
+                gm = 0.0 if (global_max is None or global_max <= 0) else float(global_max)
+                _capi.check(_capi.lib().sg_normalise_image(
+                    C.c_void_p(self.buf.ptr), self.dtype_code, self.rows, self.n_bins, k_lo, k_hi, int(bool(log_scale)),
+                    gm, C.c_void_p(d_img.ptr), C.c_void_p(self._scratch.ptr), None))
+                _capi.check(_capi.lib().sg_colormap(C.c_void_p(d_img.ptr), n, C.c_void_p(d_lut.ptr), C.c_void_p(d_rgba.ptr), None))
+                d_rgba.download(out)
+                _capi.stream_sync()
+            finally:
+                for b in (d_img, d_lut, d_rgba):
+                    b.free()
+        return np.moveaxis(out.reshape(*self.outer, self.n_frames, width, 4), -3, -2)
+
     def minmax(self, k_lo, k_hi):
         mm = np.empty(2, self.dtype)
         _capi.check(_capi.lib().sg_minmax(C.c_void_p(self.buf.ptr), self.dtype_code, self.rows, self.n_bins, k_lo, k_hi,

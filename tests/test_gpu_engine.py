@@ -232,3 +232,23 @@ def test_fused_stft_mel(hop, n_mels, detrend):
     fused = bank.stft_mel(x, plan)
     assert np.allclose(fused, unfused, rtol=2e-5, atol=1e-6 * unfused.max())
     dev.free(); bank.close()
+
+
+def test_device_colormap_matches_matplotlib_jet():
+    """N3 display epilogue: RGBA bytes of the normalised image equal matplotlib's own jet mapping of the same image."""
+    import matplotlib
+    matplotlib.use("Agg")
+    from matplotlib import colormaps
+    from spectro import engine
+    rng = np.random.default_rng(31)
+    x = (rng.standard_normal(30000) * 0.2).astype(np.float32)
+    dev = engine.stft(x, fs=8000.0, nperseg=512)
+    k_lo, k_hi = engine.bin_range(dev.f, 50.0, 3000.0)
+    for log in (False, True):
+        img = dev.image(k_lo, k_hi, log)
+        rgba = dev.image_rgba(k_lo, k_hi, log)
+        ref = colormaps["jet"](img, bytes=True)
+        assert rgba.shape == ref.shape == img.shape + (4,)
+        diff = np.abs(rgba.astype(int) - ref.astype(int))
+        assert diff.max() <= 1 and (diff > 0).mean() < 1e-3        # LUT identical up to float rounding at bin edges
+    dev.free()

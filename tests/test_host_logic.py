@@ -300,3 +300,15 @@ def test_mel_weights_host_function_matches_own_oracle():
             blk = w[:, 16 * t:16 * t + 16]
             nz = np.nonzero(blk.any(axis=1))[0]
             assert klo[t] <= nz[0] and khi[t] >= nz[-1] + 1 and klo[t] % 4 == 0 and khi[t] % 4 == 0
+
+
+def test_jet_lut_matches_matplotlib():
+    import ctypes as C
+    import matplotlib
+    matplotlib.use("Agg")
+    from matplotlib import colormaps
+    from spectro import _capi
+    lut = np.empty((256, 4), np.uint8)
+    _capi.check(_capi.lib().sg_jet_lut(lut.ctypes.data_as(C.POINTER(C.c_uint8))))
+    ref = (colormaps["jet"](np.arange(256)) * 255).astype(np.uint8)
+    np.testing.assert_array_equal(lut, ref)          # same arithmetic as matplotlib's lookup table builder
