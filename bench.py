@@ -12,7 +12,8 @@ is used only for the barrier and the max-over-ranks time.  Rank 0 prints ONE JSO
 
 Defaults (500 timed steps after 100 warm-up steps, ~60 ms of GPU time) are long enough to get past the chip's
 power-management transient: the first ~12 launches run at 92 us, the next ~100 at up to 138 us, then the
-clock settles (profiles/r01d_kernel_trace_durations.txt); shorter runs measure the transient, not the kernel.
+clock settles (profiles/r01e_kernel_trace_durations.txt); shorter runs measure the transient, not the kernel.
+For that reason ~60 ms of untimed launches (--settle-ms) precede the W warm-up steps whatever W and K are.
 
 PyTorch is plumbing here (device memory, streams, torch.distributed); the measured work is
 sg_stft from libspectro.so, called through the C ABI on torch's current stream.
@@ -45,6 +46,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline work")
     ap.add_argument("--kernel", default=None, help="force a kernel family (debug): r8x3 | stockham")
+    ap.add_argument("--settle-ms", type=float, default=60.0,
+                    help="untimed back-to-back launches before the warm-up steps, so that the power-management transient "
+                         "(first ~200 launches) is over whatever --warmup/--steps are (0 disables)")
     return ap.parse_args()
 
 
@@ -112,6 +116,14 @@ def main():
         b = i % N_BUFFER_SETS
         plan.stft(xs[b].data_ptr(), N_SAMPLES, N_SAMPLES, n_clips, outs[b].data_ptr(), n_frames * N_BINS, stream=stream)
 
+    if args.settle_ms > 0:                        # untimed: let the clocks settle (see module docstring)
+        t_settle = time.perf_counter()
+        i = 0
+        while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+            for _ in range(16):
+                step(i)
+                i += 1
+            torch.cuda.synchronize(dev)
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize(dev)
