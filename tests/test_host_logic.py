@@ -272,13 +272,16 @@ def test_gloo_world2_sharding(tmp_path):
     script = tmp_path / "gloo_shard.py"
     script.write_text(GLOO_SCRIPT)
     import socket
-    with socket.socket() as sk:                      # free port: parallel or repeated runs must not collide
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT, PKG],
-                       capture_output=True, text=True, timeout=300, env=env)
+    for attempt in range(2):                         # the rendezvous port can be taken between probing and binding
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                            "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT, PKG],
+                           capture_output=True, text=True, timeout=300, env=env)
+        if r.returncode == 0:
+            break
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
 
