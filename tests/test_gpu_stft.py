@@ -379,3 +379,24 @@ def test_abi_argument_errors(sp):
         plan.force_kernel("nope")
     with pytest.raises(NotImplementedError):
         plan.force_kernel("r8x3")
+
+
+def test_accuracy_against_f64_truth_not_worse_than_scipy_f32(sp):
+    """How close is each fp32 path to the f64 result on the same samples?  The device kernels must be at least as
+    accurate as the reference's own fp32 path (scipy/pocketfft in complex64), frame by frame, for every register kernel."""
+    import scipy.signal as ss
+    rng = np.random.default_rng(2)
+    x = (rng.standard_normal(200000) * 0.1).astype(np.float32)
+    for n, hop in [(256, 64), (512, 128), (1024, 256), (2048, 256), (4096, 1024)]:
+        kw = dict(fs=48000.0, nperseg=n, window="hann", noverlap=n - hop)
+        _, _, truth = ss.spectrogram(x.astype(np.float64), **kw)
+        _, _, ref32 = ss.spectrogram(x, **kw)
+        _, _, gpu = sp.spectrogram(x, **kw)
+        fmax = truth.max(axis=0, keepdims=True)
+        e_ref = np.abs(ref32 - truth) / fmax
+        e_gpu = np.abs(gpu - truth) / fmax
+        n_ref = np.linalg.norm(ref32 - truth) / np.linalg.norm(truth)
+        n_gpu = np.linalg.norm(gpu - truth) / np.linalg.norm(truth)
+        print(f"n={n}: per-frame max rel err gpu {e_gpu.max():.2e} scipy-f32 {e_ref.max():.2e}; normwise gpu {n_gpu:.2e} scipy-f32 {n_ref:.2e}")
+        assert e_gpu.max() <= max(2.0 * e_ref.max(), 2e-6)
+        assert n_gpu <= max(2.0 * n_ref, 5e-7)
