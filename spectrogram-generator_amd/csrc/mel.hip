@@ -50,7 +50,6 @@ __global__ __launch_bounds__(256) void mel_kernel(const MelParams p) {
     for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int k_full = (p.n_bins - 16) & ~15;            // blocks below this never touch the row end
-#pragma unroll 2
     for (int k0 = 0; k0 < p.k_pad; k0 += 16) {
         f32x4 a;
         if (k0 < k_full) {
