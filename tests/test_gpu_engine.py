@@ -252,3 +252,17 @@ def test_device_colormap_matches_matplotlib_jet():
         diff = np.abs(rgba.astype(int) - ref.astype(int))
         assert diff.max() <= 1 and (diff > 0).mean() < 1e-3        # LUT identical up to float rounding at bin edges
     dev.free()
+
+
+def test_sharded_sweep_single_rank_on_device():
+    """cfg4 API on one rank: every (clip, n_fft, hop) item equals the offline band log-power of the same samples."""
+    from spectro import sweep
+    rng = np.random.default_rng(17)
+    clips = (rng.standard_normal((2, 30000)) * 0.2).astype(np.float32)
+    res = sweep.sharded_sweep(clips, 48000.0, [256, 512, 1024, 2048, 4096], [64, 256], fmin=200.0, fmax=8000.0)
+    assert len(res) == 2 * 5 * 2
+    for (clip, n, h), v in res.items():
+        f, t, s = orc.spectrogram(clips[clip], fs=48000.0, nperseg=n, window="hann", noverlap=n - h)
+        m = (f >= 200.0) & (f <= 8000.0)
+        ref = np.log10(s[m].sum(axis=0) + 1e-20)
+        assert v.shape == ref.shape and np.allclose(v, ref, atol=2e-5), (clip, n, h)

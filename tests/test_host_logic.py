@@ -263,6 +263,19 @@ GLOO_SCRIPT = textwrap.dedent('''
         assert gathered is None
         eq = sd.gather_equal(torch.full((2,), float(rank)))
     assert [float(e[0]) for e in eq] == [0.0, 1.0]
+    # cfg4: sharded parameter sweep; the per-item "device call" is the oracle here (no GPU in this container)
+    from spectro import sweep
+    clips = (np.random.default_rng(9).standard_normal((3, 4000)) * 0.1).astype(np.float32)
+    def item(clip, n, h):
+        f, t, s = orc.spectrogram(clips[clip], fs=8000.0, nperseg=n, window="hann", noverlap=n - h)
+        return np.log10(s.sum(axis=0) + 1e-20).astype(np.float32)
+    res = sweep.sharded_sweep(clips, 8000.0, [128, 256, 512], [32, 64], compute=item, dst=0)
+    if rank == 0:
+        assert len(res) == 3 * 3 * 2
+        for (clip, n, h), v in res.items():
+            assert np.array_equal(v, item(clip, n, h)), (clip, n, h)
+    else:
+        assert res is None
     dist.barrier(); dist.destroy_process_group()
     print("rank", rank, "ok")
 ''')
