@@ -24,7 +24,7 @@ using namespace wavefft;
 constexpr int kS1 = 72, kS2 = 66;
 // waves per workgroup: the LDS tables are shared by the workgroup, so T = 4 (43 KiB of tables, 18 KiB slab per wave)
 // packs 6 waves into its single workgroup per CU
-template <int T> struct WavesFor { static constexpr int value = T == 4 ? 6 : 4; };
+template <int T> struct WavesFor { static constexpr int value = 6; };
 
 struct BigParams {
     const float* x;
