@@ -166,27 +166,6 @@ class DeviceBuffer:
         return arr
 
 
-class pinned:
-    """Context manager: pin numpy arrays in place for the duration of a transfer (no-op for small ones)."""
-
-    MIN_BYTES = 8 << 20
-
-    def __init__(self, *arrays):
-        self.arrays = [a for a in arrays if a is not None and a.nbytes >= self.MIN_BYTES]
-        self.done = []
-
-    def __enter__(self):
-        for a in self.arrays:
-            if lib().sg_host_register(C.c_void_p(a.ctypes.data), a.nbytes) == SG_OK:     # best effort: pageable copy still works
-                self.done.append(a)
-        return self
-
-    def __exit__(self, *exc):
-        for a in self.done:
-            lib().sg_host_unregister(C.c_void_p(a.ctypes.data))
-        return False
-
-
 def stream_sync(stream=None):
     check(lib().sg_stream_sync(C.c_void_p(stream)))
 
