@@ -400,3 +400,37 @@ def test_accuracy_against_f64_truth_not_worse_than_scipy_f32(sp):
         print(f"n={n}: per-frame max rel err gpu {e_gpu.max():.2e} scipy-f32 {e_ref.max():.2e}; normwise gpu {n_gpu:.2e} scipy-f32 {n_ref:.2e}")
         assert e_gpu.max() <= max(2.0 * e_ref.max(), 2e-6)
         assert n_gpu <= max(2.0 * n_ref, 5e-7)
+
+
+def test_long_single_clip_indexing(sp):
+    """One 300 M-sample clip (1.2 GB in, 2.4 GB of PSD out, 1.17 M frames): 64-bit frame/sample indexing.  Checked by
+    size-independent properties: Parseval on frames near the start, middle and the very end, and periodicity (the signal
+    is a 2^20-sample block repeated, so frames 4096 hops apart are identical)."""
+    import ctypes as C
+    from spectro import _capi, engine
+    from spectro.windows import get_window
+    rng = np.random.default_rng(77)
+    block = (rng.standard_normal(1 << 20) * 0.1).astype(np.float32)
+    reps = 286
+    x = np.tile(block, reps)                                   # 299.9 M samples
+    dev = engine.stft(x, fs=48000.0, nperseg=1024, window="hann", noverlap=768)
+    n_frames = (len(x) - 1024) // 256 + 1
+    assert dev.n_frames == n_frames and len(dev.t) == n_frames
+    assert dev.t[-1] == (512 + (n_frames - 1) * 256.0) / 48000.0
+    w = get_window("hann", 1024)
+    rows = np.empty((1, 513), np.float32)
+
+    def frame(fr):
+        _capi.check(_capi.lib().sg_memcpy_d2h(rows.ctypes.data_as(C.c_void_p), C.c_void_p(dev.buf.ptr + fr * 513 * 4), 513 * 4, None))
+        _capi.stream_sync()
+        return rows[0].astype(np.float64).copy()
+
+    for fr in (0, 1, n_frames // 2 + 3, n_frames - 2, n_frames - 1):
+        seg = x[fr * 256: fr * 256 + 1024].astype(np.float64)
+        seg = (seg - seg.mean()) * w
+        lhs = frame(fr).sum() * 48000.0 * (w * w).sum() / 1024
+        assert abs(lhs - (seg ** 2).sum()) <= 2e-5 * (seg ** 2).sum(), fr
+    period = (1 << 20) // 256
+    a, b = frame(1234), frame(1234 + 200 * period)
+    np.testing.assert_array_equal(a, b)
+    dev.free()
