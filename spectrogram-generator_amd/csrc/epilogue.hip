@@ -3,37 +3,15 @@
 // log-power features), :686-719 (absolute / relative band powers).  All HBM-bound; one pass each.
 #include "spectro_internal.h"
 
+#include <cstdint>
+#include <map>
+#include <mutex>
+#include <utility>
+
 namespace sg {
 namespace {
 
 constexpr int kThreads = 256;
-
-// order-preserving float <-> unsigned key so that atomicMin/Max on integers order floats
-template <typename T> struct Key;
-template <> struct Key<float> {
-    using U = unsigned int;
-    static __device__ __forceinline__ U enc(float f) {
-        const U b = __builtin_bit_cast(U, f);
-        return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-    }
-    static __device__ __forceinline__ float dec(U k) {
-        const U b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
-        return __builtin_bit_cast(float, b);
-    }
-    static constexpr U kMaxKey = 0xffffffffu;
-};
-template <> struct Key<double> {
-    using U = unsigned long long;
-    static __device__ __forceinline__ U enc(double f) {
-        const U b = __builtin_bit_cast(U, f);
-        return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
-    }
-    static __device__ __forceinline__ double dec(U k) {
-        const U b = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
-        return __builtin_bit_cast(double, b);
-    }
-    static constexpr U kMaxKey = 0xffffffffffffffffull;
-};
 
 template <typename T>
 __device__ __forceinline__ T wave_min(T v) {
@@ -51,38 +29,88 @@ __device__ __forceinline__ T wave_add(T v) {
     return v;
 }
 
-template <typename T>
-__global__ void minmax_init_kernel(typename Key<T>::U* mm) {
-    mm[0] = Key<T>::kMaxKey;
-    mm[1] = 0;
-}
+// Reductions run in two stages: every workgroup leaves one partial in a per-stream scratch buffer, a single
+// workgroup folds the partials.  (16 K same-address atomics cost 180 us on this part -- four times the HBM
+// pass they would guard -- and the two-stage result does not depend on arrival order.)
+constexpr int kMaxParts = 2048;
 
-template <typename T>
-__global__ __launch_bounds__(kThreads) void minmax_kernel(const T* spec, int64_t n_frames, int n_bins, int k_lo, int width,
-                                                          typename Key<T>::U* mm) {
-    const int64_t total = n_frames * width;
+// All band kernels walk the spectrum one wavefront per row, lanes striding over the bins of the band: no per-element
+// 64-bit division, 256 contiguous bytes per wave-instruction on a wide band.  A band that spans every bin is one
+// contiguous array; it is then re-cut into rows of kFlatRow elements (last one ragged) and read 16 B per lane.
+struct Rows {
+    int64_t n_rows;      // rows to walk
+    int64_t pitch;       // elements between row starts in the spectrum
+    int width;           // elements per row (and the row pitch of a packed output)
+    int last_width;      // elements in the last row
+};
+constexpr int kFlatRow = 2048;
+
+template <typename T> struct Vec16;
+template <> struct Vec16<float> { using type = float4; static constexpr int N = 4; };
+template <> struct Vec16<double> { using type = double2; static constexpr int N = 2; };
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kThreads) void minmax_kernel(const T* spec, Rows r, T* parts) {
+    using V = typename Vec16<T>::type;
+    constexpr int N = VEC ? Vec16<T>::N : 1;
+    __shared__ T part[2][kThreads / 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t wave = static_cast<int64_t>(blockIdx.x) * (kThreads / 64) + wv;
+    const int64_t n_waves = static_cast<int64_t>(gridDim.x) * (kThreads / 64);
     T lo = INFINITY, hi = -INFINITY;
-    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
-         i += static_cast<int64_t>(gridDim.x) * kThreads) {
-        const int64_t f = i / width;
-        const int k = static_cast<int>(i - f * width) + k_lo;
-        const T v = spec[f * n_bins + k];
-        lo = v < lo ? v : lo;
-        hi = v > hi ? v : hi;
+    for (int64_t f = wave; f < r.n_rows; f += n_waves) {
+        const T* const row = spec + f * r.pitch;
+        const int w = f == r.n_rows - 1 ? r.last_width : r.width;
+        for (int k = lane * N; k < w; k += 64 * N) {
+            if (VEC && k + N <= w) {
+                const V v = *reinterpret_cast<const V*>(row + k);
+                const T* const e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+                for (int i = 0; i < N; ++i) { lo = e[i] < lo ? e[i] : lo; hi = e[i] > hi ? e[i] : hi; }
+            } else {
+                for (int i = 0; i < N && k + i < w; ++i) {
+                    const T v = row[k + i];
+                    lo = v < lo ? v : lo;
+                    hi = v > hi ? v : hi;
+                }
+            }
+        }
     }
     lo = wave_min(lo);
     hi = wave_max(hi);
-    if ((threadIdx.x & 63) == 0) {
-        atomicMin(&mm[0], Key<T>::enc(lo));
-        atomicMax(&mm[1], Key<T>::enc(hi));
+    if (lane == 0) { part[0][wv] = lo; part[1][wv] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kThreads / 64; ++w) {
+            lo = part[0][w] < lo ? part[0][w] : lo;
+            hi = part[1][w] > hi ? part[1][w] : hi;
+        }
+        parts[2 * blockIdx.x] = lo;
+        parts[2 * blockIdx.x + 1] = hi;
     }
 }
 
 template <typename T>
-__global__ void minmax_decode_kernel(typename Key<T>::U* mm) {
-    const T lo = Key<T>::dec(mm[0]), hi = Key<T>::dec(mm[1]);
-    reinterpret_cast<T*>(mm)[0] = lo;
-    reinterpret_cast<T*>(mm)[1] = hi;
+__global__ __launch_bounds__(kThreads) void minmax_fold_kernel(const T* parts, int n_parts, T* mm) {
+    __shared__ T part[2][kThreads / 64];
+    T lo = INFINITY, hi = -INFINITY;
+    for (int i = threadIdx.x; i < n_parts; i += kThreads) {
+        const T a = parts[2 * i], b = parts[2 * i + 1];
+        lo = a < lo ? a : lo;
+        hi = b > hi ? b : hi;
+    }
+    lo = wave_min(lo);
+    hi = wave_max(hi);
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = lo; part[1][threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kThreads / 64; ++w) {
+            lo = part[0][w] < lo ? part[0][w] : lo;
+            hi = part[1][w] > hi ? part[1][w] : hi;
+        }
+        mm[0] = lo;
+        mm[1] = hi;
+    }
 }
 
 template <typename T> __device__ __forceinline__ T t_log10(T v);
@@ -102,9 +130,10 @@ __device__ __forceinline__ T norm_db(T s, T base) {
 }
 
 // A9/A10 in one pass given the band's min/max (PlotEngine.py:126-131)
-template <typename T>
-__global__ __launch_bounds__(kThreads) void normalise_kernel(const T* spec, int64_t n_frames, int n_bins, int k_lo, int width,
-                                                             int log_scale, T global_max, const T* mm, T* img) {
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kThreads) void normalise_kernel(const T* spec, Rows r, int log_scale, T global_max, const T* mm, T* img) {
+    using V = typename Vec16<T>::type;
+    constexpr int N = VEC ? Vec16<T>::N : 1;
     const T smin = mm[0], smax = mm[1];
     const T base = global_max > T(0) ? global_max : smax;
     T db_lo = T(0), range = T(1);
@@ -114,27 +143,38 @@ __global__ __launch_bounds__(kThreads) void normalise_kernel(const T* spec, int6
         range = norm_db(smax, base) - db_lo;
         degenerate = !(range > T(1e-6));
     }
-    const int64_t total = n_frames * width;
-    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
-         i += static_cast<int64_t>(gridDim.x) * kThreads) {
-        const int64_t f = i / width;
-        const int k = static_cast<int>(i - f * width) + k_lo;
-        const T s = spec[f * n_bins + k];
-        T v;
-        if (!log_scale) v = norm_lin(s, base);
-        else v = degenerate ? T(0) : (norm_db(s, base) - db_lo) / range;
-        img[i] = v;
+    auto map = [&](T s) -> T {
+        if (!log_scale) return norm_lin(s, base);
+        return degenerate ? T(0) : (norm_db(s, base) - db_lo) / range;
+    };
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = static_cast<int64_t>(blockIdx.x) * (kThreads / 64) + (threadIdx.x >> 6);
+    const int64_t n_waves = static_cast<int64_t>(gridDim.x) * (kThreads / 64);
+    for (int64_t f = wave; f < r.n_rows; f += n_waves) {
+        const T* const row = spec + f * r.pitch;
+        T* const orow = img + f * r.width;
+        const int w = f == r.n_rows - 1 ? r.last_width : r.width;
+        for (int k = lane * N; k < w; k += 64 * N) {
+            if (VEC && k + N <= w) {
+                V v = *reinterpret_cast<const V*>(row + k);
+                T* const e = reinterpret_cast<T*>(&v);
+#pragma unroll
+                for (int i = 0; i < N; ++i) e[i] = map(e[i]);
+                *reinterpret_cast<V*>(orow + k) = v;
+            } else {
+                for (int i = 0; i < N && k + i < w; ++i) orow[k + i] = map(row[k + i]);
+            }
+        }
     }
 }
 
 template <typename T>
 __global__ __launch_bounds__(kThreads) void slice_kernel(const T* spec, int64_t n_frames, int n_bins, int k_lo, int width, T* dst) {
-    const int64_t total = n_frames * width;
-    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
-         i += static_cast<int64_t>(gridDim.x) * kThreads) {
-        const int64_t f = i / width;
-        dst[i] = spec[f * n_bins + (i - f * width) + k_lo];
-    }
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = static_cast<int64_t>(blockIdx.x) * (kThreads / 64) + (threadIdx.x >> 6);
+    const int64_t n_waves = static_cast<int64_t>(gridDim.x) * (kThreads / 64);
+    for (int64_t f = wave; f < n_frames; f += n_waves)
+        for (int k = lane; k < width; k += 64) dst[f * width + k] = spec[f * n_bins + k_lo + k];
 }
 
 // one wavefront per frame
@@ -162,32 +202,75 @@ __global__ __launch_bounds__(kThreads) void band_features_kernel(const T* band, 
     }
 }
 
-struct Bands { int n; int lo[16]; int hi[16]; };
+constexpr int kRowsPerStep = 8;
+struct Bands { int n; int k_begin; int k_end; int lo[16]; int hi[16]; };     // [lo, hi) each; [k_begin, k_end) their hull
 
+// A13: every band total from one read of the rows.  A wave takes kRowsPerStep rows at a time, 64 bins per step:
+// the rows' (clamped) values are added first, and only the bands that touch the 64-bin chunk (a wave-uniform test,
+// shared by the rows -- the scalar unit is per CU and was the bound when every row paid for it) cost vector work.
 template <typename T>
-__global__ __launch_bounds__(kThreads) void band_totals_kernel(const T* spec, int64_t n_frames, int n_bins, Bands b, double* sums) {
-    __shared__ double part[kThreads / 64];
-    for (int ib = 0; ib < b.n; ++ib) {
-        const int lo = b.lo[ib], width = b.hi[ib] - b.lo[ib];
-        double acc = 0.0;
-        if (width > 0) {
-            const int64_t total = n_frames * width;
-            for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
-                 i += static_cast<int64_t>(gridDim.x) * kThreads) {
-                const int64_t f = i / width;
-                const T v = spec[f * n_bins + (i - f * width) + lo];
-                acc += v > T(0) ? static_cast<double>(v) : 0.0;
+__global__ __launch_bounds__(kThreads) void band_totals_kernel(const T* spec, int64_t n_frames, int n_bins, Bands b, double* parts) {
+    constexpr int R = kRowsPerStep;
+    __shared__ double part[16][kThreads / 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t wave = static_cast<int64_t>(blockIdx.x) * (kThreads / 64) + wv;
+    const int64_t n_waves = static_cast<int64_t>(gridDim.x) * (kThreads / 64);
+    double acc[16];
+#pragma unroll
+    for (int ib = 0; ib < 16; ++ib) acc[ib] = 0.0;
+    const int c_begin = b.k_begin & ~63;
+    for (int64_t f0 = wave * R; f0 < n_frames; f0 += n_waves * R) {
+        const T* const rows = spec + f0 * n_bins;
+        const int nr = n_frames - f0 < R ? static_cast<int>(n_frames - f0) : R;
+        T seg[16];                                 // a lane's share of R rows (few terms); row groups add up in double
+#pragma unroll
+        for (int ib = 0; ib < 16; ++ib) seg[ib] = T(0);
+        for (int c = c_begin; c < b.k_end; c += 64) {
+            const int k = c + lane;
+            const bool in = k >= b.k_begin && k < b.k_end;
+            T v[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[r] = (in && r < nr) ? rows[static_cast<int64_t>(r) * n_bins + k] : T(0);
+            T x = T(0);
+#pragma unroll
+            for (int r = 0; r < R; ++r) x += v[r] > T(0) ? v[r] : T(0);
+#pragma unroll
+            for (int ib = 0; ib < 16; ++ib) {
+                if (ib >= b.n) break;
+                if (b.hi[ib] > c && b.lo[ib] < c + 64) seg[ib] += (k >= b.lo[ib] && k < b.hi[ib]) ? x : T(0);
             }
         }
-        acc = wave_add(acc);
-        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double t = 0.0;
-            for (int w = 0; w < kThreads / 64; ++w) t += part[w];
-            if (t != 0.0) atomicAdd(&sums[ib], t);
+#pragma unroll
+        for (int ib = 0; ib < 16; ++ib)
+            if (ib < b.n) acc[ib] += static_cast<double>(seg[ib]);
+    }
+#pragma unroll
+    for (int ib = 0; ib < 16; ++ib) {
+        if (ib < b.n) {
+            const double t = wave_add(acc[ib]);
+            if (lane == 0) part[ib][wv] = t;
         }
-        __syncthreads();
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        double t = 0.0;
+        if (threadIdx.x < b.n)
+            for (int w = 0; w < kThreads / 64; ++w) t += part[threadIdx.x][w];
+        parts[16 * blockIdx.x + threadIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void band_totals_fold_kernel(const double* parts, int n_parts, int n_bands, double* sums) {
+    __shared__ double part[16][16];
+    const int ib = threadIdx.x & 15, sub = threadIdx.x >> 4;           // 16 bands x 16 strided sub-sums
+    double t = 0.0;
+    for (int i = sub; i < n_parts; i += 16) t += parts[16 * i + ib];
+    part[sub][ib] = t;
+    __syncthreads();
+    if (threadIdx.x < n_bands) {
+        double tot = 0.0;
+        for (int j = 0; j < 16; ++j) tot += part[j][threadIdx.x];
+        sums[threadIdx.x] = tot;
     }
 }
 
@@ -224,15 +307,45 @@ inline int after_launch(const char* what) {
     return e == hipSuccess ? SG_OK : hip_fail(e, what);
 }
 
+// Scratch for the partials, one small buffer per (device, stream): launches on a stream are ordered, so successive
+// reductions on it may share the buffer.  Lives until the library is unloaded.
+void* reduction_scratch(hipStream_t s) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, void*> pool;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    void*& p = pool[{dev, s}];
+    if (!p && hipMalloc(&p, sizeof(double) * 16 * kMaxParts) != hipSuccess) p = nullptr;
+    return p;
+}
+
+// how to walk band [k_lo, k_hi] of an (n_frames x n_bins) spectrum; `flat` = the band is every bin, so the data
+// is contiguous and both it and a packed output can be read 16 B per lane
+inline Rows rows_for(int64_t n_frames, int n_bins, int k_lo, int k_hi, bool* flat) {
+    const int width = k_hi - k_lo + 1;
+    *flat = width == n_bins && n_frames > 0;
+    if (!*flat) return Rows{n_frames, n_bins, width, width};
+    const int64_t total = n_frames * n_bins;
+    const int64_t n_rows = (total + kFlatRow - 1) / kFlatRow;
+    return Rows{n_rows, kFlatRow, kFlatRow, static_cast<int>(total - (n_rows - 1) * kFlatRow)};
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 template <typename T>
 int minmax_t(const void* spec, int64_t n_frames, int n_bins, int k_lo, int k_hi, void* mm, hipStream_t s) {
-    using U = typename Key<T>::U;
-    const int width = k_hi - k_lo + 1;
-    hipLaunchKernelGGL(minmax_init_kernel<T>, dim3(1), dim3(1), 0, s, static_cast<U*>(mm));
-    if (n_frames > 0)
-        hipLaunchKernelGGL(minmax_kernel<T>, dim3(grid_for(n_frames * width)), dim3(kThreads), 0, s,
-                           static_cast<const T*>(spec), n_frames, n_bins, k_lo, width, static_cast<U*>(mm));
-    hipLaunchKernelGGL(minmax_decode_kernel<T>, dim3(1), dim3(1), 0, s, static_cast<U*>(mm));
+    T* const parts = static_cast<T*>(reduction_scratch(s));
+    if (!parts) { set_error("minmax: no scratch memory"); return SG_ERR_HIP; }
+    bool flat;
+    const Rows r = rows_for(n_frames, n_bins, k_lo, k_hi, &flat);
+    const T* const src = static_cast<const T*>(spec) + (flat ? 0 : k_lo);
+    const unsigned g = n_frames > 0 ? grid_for(r.n_rows * 64, kMaxParts) : 0;
+    if (g && flat && aligned16(src))
+        hipLaunchKernelGGL((minmax_kernel<T, true>), dim3(g), dim3(kThreads), 0, s, src, r, parts);
+    else if (g)
+        hipLaunchKernelGGL((minmax_kernel<T, false>), dim3(g), dim3(kThreads), 0, s, src, r, parts);
+    hipLaunchKernelGGL(minmax_fold_kernel<T>, dim3(1), dim3(kThreads), 0, s, parts, static_cast<int>(g), static_cast<T*>(mm));
     return after_launch("minmax");
 }
 
@@ -241,10 +354,16 @@ int normalise_t(const void* spec, int64_t n_frames, int n_bins, int k_lo, int k_
                 void* img, void* mm, hipStream_t s) {
     int rc = minmax_t<T>(spec, n_frames, n_bins, k_lo, k_hi, mm, s);
     if (rc != SG_OK || n_frames == 0) return rc;
-    const int width = k_hi - k_lo + 1;
-    hipLaunchKernelGGL(normalise_kernel<T>, dim3(grid_for(n_frames * width)), dim3(kThreads), 0, s,
-                       static_cast<const T*>(spec), n_frames, n_bins, k_lo, width, log_scale, static_cast<T>(gmax),
-                       static_cast<const T*>(mm), static_cast<T*>(img));
+    bool flat;
+    const Rows r = rows_for(n_frames, n_bins, k_lo, k_hi, &flat);
+    const T* const src = static_cast<const T*>(spec) + (flat ? 0 : k_lo);
+    const unsigned g = grid_for(r.n_rows * 64);
+    if (flat && aligned16(src) && aligned16(img))
+        hipLaunchKernelGGL((normalise_kernel<T, true>), dim3(g), dim3(kThreads), 0, s, src, r, log_scale, static_cast<T>(gmax),
+                           static_cast<const T*>(mm), static_cast<T*>(img));
+    else
+        hipLaunchKernelGGL((normalise_kernel<T, false>), dim3(g), dim3(kThreads), 0, s, src, r, log_scale, static_cast<T>(gmax),
+                           static_cast<const T*>(mm), static_cast<T*>(img));
     return after_launch("normalise");
 }
 
@@ -324,10 +443,10 @@ int sg_slice_bins(const void* spec_dev, int dtype, int64_t n_frames, int n_bins,
     auto s = static_cast<hipStream_t>(stream);
     const int width = k_hi - k_lo + 1;
     if (dtype == SG_F32)
-        hipLaunchKernelGGL(slice_kernel<float>, dim3(grid_for(n_frames * width)), dim3(kThreads), 0, s,
+        hipLaunchKernelGGL(slice_kernel<float>, dim3(grid_for(n_frames * 64)), dim3(kThreads), 0, s,
                            static_cast<const float*>(spec_dev), n_frames, n_bins, k_lo, width, static_cast<float*>(dst_dev));
     else if (dtype == SG_F64)
-        hipLaunchKernelGGL(slice_kernel<double>, dim3(grid_for(n_frames * width)), dim3(kThreads), 0, s,
+        hipLaunchKernelGGL(slice_kernel<double>, dim3(grid_for(n_frames * 64)), dim3(kThreads), 0, s,
                            static_cast<const double*>(spec_dev), n_frames, n_bins, k_lo, width, static_cast<double*>(dst_dev));
     else { set_error("bad dtype %d", dtype); return SG_ERR_ARG; }
     return after_launch("slice_bins");
@@ -377,18 +496,24 @@ int sg_band_totals(const void* spec_dev, int dtype, int64_t n_frames, int n_bins
         if (hi < lo) hi = lo;
         b.lo[i] = lo;
         b.hi[i] = hi;
+        if (hi > lo) {
+            if (b.k_end == 0 || lo < b.k_begin) b.k_begin = lo;
+            if (hi > b.k_end) b.k_end = hi;
+        }
     }
     auto s = static_cast<hipStream_t>(stream);
-    SG_HIP(hipMemsetAsync(sums_dev, 0, sizeof(double) * n_bands, s));
-    if (n_frames == 0) return SG_OK;
-    const unsigned g = grid_for(n_frames * n_bins, 256 * 4);
+    if (n_frames == 0) { SG_HIP(hipMemsetAsync(sums_dev, 0, sizeof(double) * n_bands, s)); return SG_OK; }
+    double* const parts = static_cast<double*>(reduction_scratch(s));
+    if (!parts) { set_error("band_totals: no scratch memory"); return SG_ERR_HIP; }
+    const unsigned g = grid_for((n_frames + kRowsPerStep - 1) / kRowsPerStep * 64, kMaxParts);
     if (dtype == SG_F32)
         hipLaunchKernelGGL(band_totals_kernel<float>, dim3(g), dim3(kThreads), 0, s, static_cast<const float*>(spec_dev), n_frames,
-                           n_bins, b, sums_dev);
+                           n_bins, b, parts);
     else if (dtype == SG_F64)
         hipLaunchKernelGGL(band_totals_kernel<double>, dim3(g), dim3(kThreads), 0, s, static_cast<const double*>(spec_dev), n_frames,
-                           n_bins, b, sums_dev);
+                           n_bins, b, parts);
     else { set_error("bad dtype %d", dtype); return SG_ERR_ARG; }
+    hipLaunchKernelGGL(band_totals_fold_kernel, dim3(1), dim3(kThreads), 0, s, parts, static_cast<int>(g), n_bands, sums_dev);
     return after_launch("band_totals");
 }
 

@@ -266,3 +266,54 @@ def test_sharded_sweep_single_rank_on_device():
         m = (f >= 200.0) & (f <= 8000.0)
         ref = np.log10(s[m].sum(axis=0) + 1e-20)
         assert v.shape == ref.shape and np.allclose(v, ref, atol=2e-5), (clip, n, h)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_epilogue_abi_random_shapes(dtype):
+    """A8-A13 through the C ABI on ragged shapes: every bin (the contiguous 16 B/lane walk, also from a pointer
+    that is not 16 B aligned), sub-bands, one-bin bands, overlapping / empty / clipped band tables."""
+    import ctypes as C
+    from spectro import _capi
+    _capi.ensure_device()
+    L = _capi.lib()
+    code = 0 if dtype == np.float32 else 1
+    rng = np.random.default_rng(77)
+    isz = np.dtype(dtype).itemsize
+    for rows, nb, off in [(1, 1, 0), (7, 65, 0), (1000, 129, 0), (333, 513, 0), (333, 513, 1), (40, 2049, 0), (5, 5000, 1)]:
+        host = (rng.random((rows, nb)) ** 8).astype(dtype) + dtype(1e-6)
+        host[rng.integers(rows), rng.integers(nb)] = 3.0
+        buf = _capi.DeviceBuffer((rows * nb + 4) * isz)
+        flat = np.zeros(rows * nb + 4, dtype)
+        flat[off:off + rows * nb] = host.ravel()
+        buf.upload(flat)
+        spec = C.c_void_p(buf.ptr + off * isz)
+        img = _capi.DeviceBuffer(rows * nb * isz)
+        mm = _capi.DeviceBuffer(64)
+        sums = _capi.DeviceBuffer(16 * 8)
+        bands = [(0, nb - 1), (nb // 3, nb // 3), (nb // 4, (3 * nb) // 4), (nb - 1, nb - 1)]
+        for k_lo, k_hi in bands:
+            w = k_hi - k_lo + 1
+            ref = host[:, k_lo:k_hi + 1]
+            _capi.check(L.sg_minmax(spec, code, rows, nb, k_lo, k_hi, C.c_void_p(mm.ptr), None))
+            got = mm.download(np.zeros(2, dtype)); _capi.stream_sync()
+            assert got[0] == ref.min() and got[1] == ref.max()
+            out = np.zeros((rows, w), dtype)
+            _capi.check(L.sg_slice_bins(spec, code, rows, nb, k_lo, k_hi, C.c_void_p(img.ptr), None))
+            img.download(out); _capi.stream_sync()
+            np.testing.assert_array_equal(out, ref)
+            for log, gmax in [(0, 0.0), (1, 0.0), (1, 7.5)]:
+                _capi.check(L.sg_normalise_image(spec, code, rows, nb, k_lo, k_hi, log, gmax, C.c_void_p(img.ptr),
+                                                 C.c_void_p(mm.ptr), None))
+                img.download(out); _capi.stream_sync()
+                want = orc.plot_image(np.arange(w, dtype=float), np.arange(rows, dtype=float), ref.T.astype(np.float64),
+                                      -1.0, w + 1.0, bool(log), gmax if gmax > 0 else None)[3].T
+                assert np.abs(out - want).max() <= (2e-4 if dtype == np.float32 else 1e-9)
+        table = [(0, nb), (0, 1), (nb // 3, nb // 2), (nb // 4, nb), (5, 5), (-3, 2), (nb - 1, nb + 9), (nb // 2, nb // 2 + 1)]
+        lo = (C.c_int * len(table))(*[a for a, _ in table]); hi = (C.c_int * len(table))(*[b for _, b in table])
+        _capi.check(L.sg_band_totals(spec, code, rows, nb, len(table), lo, hi, C.c_void_p(sums.ptr), None))
+        got = sums.download(np.zeros(len(table))); _capi.stream_sync()
+        h64 = host.astype(np.float64)
+        want = [h64[:, max(a, 0):min(b, nb)].sum() if min(b, nb) > max(a, 0) else 0.0 for a, b in table]
+        assert np.allclose(got, want, rtol=1e-6 if dtype == np.float32 else 1e-13, atol=0)
+        for b_ in (buf, img, mm, sums):
+            b_.free()
