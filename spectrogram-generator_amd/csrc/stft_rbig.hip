@@ -9,6 +9,9 @@
 //   pass 3: lane l runs T radix-8 butterflies over j0 and ends with Z[l + 64c], c = q3 + T*t in d[q3][t]
 // and the split pass pairs k = l + 64c (c < R/2, registers) with M - k (upper half, through LDS).
 // Window and twiddle tables live in LDS (one copy per workgroup).  Index maps and bank behaviour: tools/sim_rbig.py.
+// Every exchange moves 8 registers per lane at a time through ONE 4.5 KiB slab per wave (a wave's DS operations
+// execute in issue order, so the slab is reused back to back without waiting): 12 (T = 4) / 16 (T = 2) waves per CU
+// instead of the 6 a whole-frame slab allowed -- the kernel was latency-bound at 1.5 waves per SIMD.
 // Algorithmic HBM bytes per frame: hop*4 + (512T+1)*4.
 #include "spectro_internal.h"
 #include "fft_wave.h"
@@ -22,9 +25,10 @@ namespace {
 using namespace wavefft;
 
 constexpr int kS1 = 72, kS2 = 66;
-// waves per workgroup: the LDS tables are shared by the workgroup, so T = 4 (43 KiB of tables, 18 KiB slab per wave)
-// packs 6 waves into its single workgroup per CU
-template <int T> struct WavesFor { static constexpr int value = 6; };
+// waves per workgroup (the LDS tables are shared by the workgroup): T = 4 -> one workgroup of 12 waves per CU
+// (43 KiB of tables + 12 x 4.5 KiB, 142 VGPRs = 3 waves/SIMD); T = 2 -> two workgroups of 8 (21 + 36 KiB each)
+template <int T> struct WavesFor { static constexpr int value = T == 4 ? 12 : 8; };
+constexpr int kSlabElems = 8 * kS1;                          // one 8-register exchange group (576 float2)
 
 struct BigParams {
     const float* x;
@@ -60,9 +64,9 @@ template <int R> __device__ __forceinline__ float2 const_tw(int n) {
 }
 
 template <int T, bool DETREND, int MODE>
-__global__ __launch_bounds__(64 * WavesFor<T>::value) void stft_rbig_kernel(const BigParams p) {
+__global__ __launch_bounds__(64 * WavesFor<T>::value, T == 4 ? 3 : 4) void stft_rbig_kernel(const BigParams p) {
     constexpr int R = 8 * T, M = 64 * R, NB = M + 1, kWaves = WavesFor<T>::value;
-    constexpr int kSlab = T * 8 * kS1;                       // complex elements per wave
+    constexpr int kSlab = kSlabElems;                        // complex elements per wave
     constexpr int kTw1 = M, kTw2 = kTw1 + (R - 1) * 64, kTw3 = kTw2 + 7 * 64, kTabs = kTw3 + (R / 2) * 64;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int lane = threadIdx.x & 63;
@@ -83,12 +87,12 @@ __global__ __launch_bounds__(64 * WavesFor<T>::value) void stft_rbig_kernel(cons
     const float2* const t2 = lds + kTw2 + lane;              // + 64*(s-1)
     const float2* const t3 = lds + kTw3 + lane;              // + 64*c
     const int j0 = lane & 7, hi = lane >> 3;
-    float2* const x1w = buf + hi * kS1 + j0;                 // + q*8*kS1 + 8*r1
-    float2* const x1r = buf + lane;                          // + q*8*kS1 + b*kS1
-    float2* const x2w = buf + j0 * kS2 + hi;                 // + q3*8*kS2 + ((8q + R*s) % 64)
-    float2* const x2r = buf + lane;                          // + q3*8*kS2 + j0*kS2
-    float2* const x3w = buf + lane;                          // + 64*c
-    const float2* const x3b = buf + (M - lane);              // - 64*c
+    float2* const x1w = buf + hi * kS1 + j0;                 // + 8*r1            (group q)
+    float2* const x1r = buf + lane;                          // + b*kS1
+    float2* const x2w = buf + j0 * kS2 + hi;                 // + ((8q + R*s) % 64)   (group q3 = (8q + R*s) / 64)
+    float2* const x2r = buf + lane;                          // + j*kS2
+    float2* const x3w = buf + lane;                          // + 64*slot, 4 upper blocks per group
+    const float2* const x3b = buf + (256 - lane);            // - 64*(c - 4i)
 
     const float q_in = MODE == 0 ? p.scale * 0.5f : p.scale * 0.25f;
     const float q0 = lane == 0 ? p.scale * 0.25f : q_in;
@@ -96,22 +100,22 @@ __global__ __launch_bounds__(64 * WavesFor<T>::value) void stft_rbig_kernel(cons
     // T = 2: the 16 float2 of frame g+1 are fetched before the FFT of frame g (register prefetch, +32 VGPRs);
     // T = 4 has no registers to spare and loads at the top of the frame.
     constexpr bool kPrefetch = T == 2;
-    auto load_frame = [&](int64_t gg, float2 (&dst)[T][8]) {
-        const int clip = static_cast<int>(gg / p.n_frames);
-        const int f = static_cast<int>(gg - static_cast<int64_t>(clip) * p.n_frames);
+    auto load_frame = [&](int clip, int f, float2 (&dst)[T][8]) {
         const float* const src = p.x + static_cast<int64_t>(clip) * p.clip_stride + static_cast<int64_t>(f) * p.hop + 2 * lane;
 #pragma unroll
         for (int a0 = 0; a0 < T; ++a0)
 #pragma unroll
             for (int a1 = 0; a1 < 8; ++a1) dst[a0][a1] = *reinterpret_cast<const float2*>(src + 128 * (a0 + T * a1));
     };
+    // (clip, frame) of the run's first frame by one division; after that they advance incrementally
+    int clip = static_cast<int>(g / p.n_frames);
+    int f = static_cast<int>(g - static_cast<int64_t>(clip) * p.n_frames);
     float2 nxt[kPrefetch ? T : 1][8];
-    if (kPrefetch && g < g_end) load_frame(g, reinterpret_cast<float2 (&)[T][8]>(nxt));
+    if (kPrefetch && g < g_end) load_frame(clip, f, reinterpret_cast<float2 (&)[T][8]>(nxt));
 
     for (; g < g_end; ++g) {
-        const int clip = static_cast<int>(g / p.n_frames);
-        const int f = static_cast<int>(g - static_cast<int64_t>(clip) * p.n_frames);
         float* const orow = p.out + static_cast<int64_t>(clip) * p.out_clip_stride + static_cast<int64_t>(f) * NB;
+        const int clip_n = f + 1 == p.n_frames ? clip + 1 : clip, f_n = f + 1 == p.n_frames ? 0 : f + 1;
 
         float2 d[T][8];
         if (kPrefetch) {
@@ -119,10 +123,12 @@ __global__ __launch_bounds__(64 * WavesFor<T>::value) void stft_rbig_kernel(cons
             for (int a0 = 0; a0 < T; ++a0)
 #pragma unroll
                 for (int a1 = 0; a1 < 8; ++a1) d[a0][a1] = nxt[kPrefetch ? a0 : 0][a1];
-            if (g + 1 < g_end) load_frame(g + 1, reinterpret_cast<float2 (&)[T][8]>(nxt));
+            if (g + 1 < g_end) load_frame(clip_n, f_n, reinterpret_cast<float2 (&)[T][8]>(nxt));
         } else {
-            load_frame(g, d);
+            load_frame(clip, f, d);
         }
+        clip = clip_n;
+        f = f_n;
 
         if (DETREND) {
             float s = 0.f;
@@ -168,15 +174,14 @@ __global__ __launch_bounds__(64 * WavesFor<T>::value) void stft_rbig_kernel(cons
             for (int r1 = 0; r1 < 8; ++r1)
                 if (q + r1 > 0) d[q][r1] = cmul(d[q][r1], lds_get(t1 + 64 * (r1 + 8 * q - 1)));
 #pragma unroll
-        for (int q = 0; q < T; ++q)
+        for (int q = 0; q < T; ++q) {                        // exchange 1, one group of 8 at a time through the slab
 #pragma unroll
-            for (int r1 = 0; r1 < 8; ++r1) lds_put(x1w + q * 8 * kS1 + 8 * r1, d[q][r1]);
-        wave_lds_fence();
+            for (int r1 = 0; r1 < 8; ++r1) lds_put(x1w + 8 * r1, d[q][r1]);
+            wave_lds_fence();
 #pragma unroll
-        for (int q = 0; q < T; ++q)
-#pragma unroll
-            for (int b = 0; b < 8; ++b) d[q][b] = lds_get(x1r + q * 8 * kS1 + b * kS1);
-        wave_lds_fence();
+            for (int b = 0; b < 8; ++b) d[q][b] = lds_get(x1r + b * kS1);
+            wave_lds_fence();
+        }
 
         // ---- pass 2 ----------------------------------------------------------------------------------------------
 #pragma unroll
@@ -185,38 +190,40 @@ __global__ __launch_bounds__(64 * WavesFor<T>::value) void stft_rbig_kernel(cons
 #pragma unroll
             for (int s = 1; s < 8; ++s) d[q][s] = cmul(d[q][s], lds_get(t2 + 64 * (s - 1)));
         }
+        float2 e[T][8];                                      // pass-3 operands: e[q3][j]
 #pragma unroll
-        for (int q = 0; q < T; ++q)
+        for (int q3 = 0; q3 < T; ++q3) {                     // exchange 2: group q3 collects the (q, s) with (8q + R*s) / 64 == q3
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const int uu = 8 * q + R * s;                // + r1 (= hi) < 8 never carries into the next 64
-                lds_put(x2w + (uu / 64) * 8 * kS2 + (uu % 64), d[q][s]);
-            }
-        wave_lds_fence();
+            for (int q = 0; q < T; ++q)
 #pragma unroll
-        for (int q3 = 0; q3 < T; ++q3)
+                for (int s = 0; s < 8; ++s) {
+                    const int uu = 8 * q + R * s;            // + r1 (= hi) < 8 never carries into the next 64
+                    if (uu / 64 == q3) lds_put(x2w + (uu % 64), d[q][s]);
+                }
+            wave_lds_fence();
 #pragma unroll
-            for (int j = 0; j < 8; ++j) d[q3][j] = lds_get(x2r + q3 * 8 * kS2 + j * kS2);
-        wave_lds_fence();
+            for (int j = 0; j < 8; ++j) e[q3][j] = lds_get(x2r + j * kS2);
+            wave_lds_fence();
+        }
 
         // ---- pass 3: d[q3][t] = Z[lane + 64*(q3 + T*t)] ---------------------------------------------------
 #pragma unroll
-        for (int q3 = 0; q3 < T; ++q3) radix8(d[q3]);
-#pragma unroll
-        for (int q3 = 0; q3 < T; ++q3)
-#pragma unroll
-            for (int t = 4; t < 8; ++t) lds_put(x3w + 64 * (q3 + T * t), d[q3][t]);
-        if (lane == 0) lds_put(buf + M, d[0][0]);
-        wave_lds_fence();
+        for (int q3 = 0; q3 < T; ++q3) radix8(e[q3]);
+#define SG_Z(c) e[(c) % T][(c) / T]                          // Z[lane + 64*c]
 
-        // ---- split pass + epilogue --------------------------------------------------------------------------
+        // ---- split pass + epilogue: lower blocks c (registers) pair with upper blocks R-1-c (and element 0 of
+        //      block R-c) of the mirrored lane; four blocks per trip through the slab ------------------------------
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int i = 0; i < R / 8; ++i) {
 #pragma unroll
-            for (int q3 = 0; q3 < T; ++q3) {
-                const int c = q3 + T * t;
-                const float2 A = d[q3][t];
-                const float2 B = lds_get(x3b - 64 * c);
+            for (int sl = 0; sl < 4; ++sl) lds_put(x3w + 64 * sl, SG_Z(R - 4 * i - 4 + sl));
+            if (lane == 0) lds_put(buf + 256, i == 0 ? SG_Z(0) : SG_Z(R - 4 * i));   // i = 0: Z[M] := Z[0]
+            wave_lds_fence();
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const int c = 4 * i + cc;
+                const float2 A = SG_Z(c);
+                const float2 B = lds_get(x3b - 64 * cc);
                 const float2 cs = lds_get(t3 + 64 * c);
                 const float2 S = make_float2(A.x + B.x, A.y - B.y);
                 const float2 D = make_float2(A.x - B.x, A.y + B.y);
@@ -230,14 +237,16 @@ __global__ __launch_bounds__(64 * WavesFor<T>::value) void stft_rbig_kernel(cons
                 orow[k] = pk;
                 orow[M - k] = pm;
             }
-        {   // k = M/2: lane 0, register c = R/2 = d[0][4]
-            const float zx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d[0][4].x), 0));
-            const float zy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d[0][4].y), 0));
+            wave_lds_fence();
+        }
+        {   // k = M/2: lane 0, block c = R/2
+            const float zx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, SG_Z(R / 2).x), 0));
+            const float zy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, SG_Z(R / 2).y), 0));
             float pq = fmaf(zx, zx, zy * zy) * (q_in * 4.0f);
             if (MODE == 1) pq = sqrtf(pq);
             orow[M / 2] = pq;                                // wave-uniform store
         }
-        wave_lds_fence();
+#undef SG_Z
     }
 }
 
@@ -263,7 +272,7 @@ int launch_t(const sg_plan& p, const StftArgs& a) {
     prm.n_frames = static_cast<int>(a.n_frames);
     prm.hop = p.hop;
     prm.total_frames = a.n_frames * a.n_clips;
-    const size_t lds = (static_cast<size_t>(M) + (R - 1 + 7 + R / 2) * 64 + static_cast<size_t>(kWaves) * T * 8 * kS1) * sizeof(float2);
+    const size_t lds = (static_cast<size_t>(M) + (R - 1 + 7 + R / 2) * 64 + static_cast<size_t>(kWaves) * kSlabElems) * sizeof(float2);
     const int wg_per_cu = static_cast<int>((160 * 1024) / lds) < 1 ? 1 : static_cast<int>((160 * 1024) / lds);
     int64_t n_waves = static_cast<int64_t>(p.n_cu) * wg_per_cu * kWaves;
     if (n_waves > prm.total_frames) n_waves = prm.total_frames;
