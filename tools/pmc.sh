@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for ctrs in "$@"; do
   i=$((i+1))
-  timeout -k 5 120 rocprofv3 --pmc $ctrs --output-format csv -d $R/gpurun_out/pmc_${tag}_$i -- python3 $R/tools/quick_bench.py 64 256 > $R/gpurun_out/pmc_${tag}_$i.log 2>&1
+  timeout -k 5 120 rocprofv3 --pmc $ctrs --output-format csv -d $R/gpurun_out/pmc_${tag}_$i -- python3 $R/tools/quick_bench.py ${QB_ARGS:-64 256} > $R/gpurun_out/pmc_${tag}_$i.log 2>&1
 done
 python3 - <<PY
 import csv,glob,collections

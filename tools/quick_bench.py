@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Quick device timing of sg_stft on the cfg2 shape (no torch): python tools/quick_bench.py [n_clips] [hop] [kernel]"""
+"""Quick device timing of sg_stft on the cfg2 shape (no torch): python tools/quick_bench.py [n_clips] [hop] [kernel|-] [nfft]"""
 import os
 import sys
 import time
@@ -12,8 +12,8 @@ from spectro.windows import get_window  # noqa: E402
 
 n_clips = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 hop = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-kernel = sys.argv[3] if len(sys.argv) > 3 else None
-N, n = 480000, 1024
+kernel = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] != "-" else None
+N, n = 480000, (int(sys.argv[4]) if len(sys.argv) > 4 else 1024)
 _capi.ensure_device()
 print(_capi.device_info())
 x = (np.random.default_rng(1234).standard_normal((n_clips, N)) * 0.1).astype(np.float32)
@@ -23,23 +23,23 @@ if kernel:
 nfr = plan.n_frames(N)
 NB = 4   # rotate buffer sets so the 256 MiB infinity cache cannot hold the working set
 ins = [_capi.DeviceBuffer(x.nbytes) for _ in range(NB)]
-outs = [_capi.DeviceBuffer(n_clips * nfr * 513 * 4) for _ in range(NB)]
+outs = [_capi.DeviceBuffer(n_clips * nfr * (n // 2 + 1) * 4) for _ in range(NB)]
 for b in ins:
     b.upload(x)
 _capi.stream_sync()
 for i in range(3):
-    plan.stft(ins[i % NB].ptr, N, N, n_clips, outs[i % NB].ptr, nfr * 513)
+    plan.stft(ins[i % NB].ptr, N, N, n_clips, outs[i % NB].ptr, nfr * (n // 2 + 1))
 _capi.stream_sync()
 frames = n_clips * nfr
 for rep in range(3):
     t0 = time.perf_counter()
     iters = 40
     for i in range(iters):
-        plan.stft(ins[i % NB].ptr, N, N, n_clips, outs[i % NB].ptr, nfr * 513)
+        plan.stft(ins[i % NB].ptr, N, N, n_clips, outs[i % NB].ptr, nfr * (n // 2 + 1))
     _capi.stream_sync()
     dt = (time.perf_counter() - t0) / iters
-    bpf = hop * 4 + 513 * 4
+    bpf = hop * 4 + (n // 2 + 1) * 4
     print(f"kernel={plan.kernel} clips={n_clips} hop={hop} frames={frames} {dt*1e6:.1f} us/launch "
           f"{frames/dt/1e6:.1f} Mframes/s  {frames*bpf/dt/1e9:.0f} GB/s algorithmic ({frames*bpf/dt/8e12*100:.1f}% of 8 TB/s)")
-ms = plan.time_stft(ins[0].ptr, N, N, n_clips, outs[0].ptr, nfr * 513, 20)
+ms = plan.time_stft(ins[0].ptr, N, N, n_clips, outs[0].ptr, nfr * (n // 2 + 1), 20)
 print(f"hipEvent single-buffer: {ms*1e3:.1f} us/launch")

@@ -5,7 +5,8 @@
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
 template <int KIND>
-__global__ __launch_bounds__(256) void k(float* out, int iters) {
+__global__ __launch_bounds__(256) void k(float* out, int iters, long long* cyc) {
+    const long long c0 = clock64();
     float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     float b = 1.0001f, c = 0.5f;
     typedef float v2 __attribute__((ext_vector_type(2)));
@@ -33,6 +34,7 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
         }
       }
     }
+    if (cyc && blockIdx.x == 0 && threadIdx.x == 0) *cyc = clock64() - c0;     // shader-clock cycles of one wave
     out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y;
 }
 
@@ -41,17 +43,18 @@ int run(const char* name, int wg_per_cu, float* out) {
     const int iters = 2000, nwg = 256 * wg_per_cu;
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(k<KIND>, dim3(nwg), dim3(256), 0, 0, out, 100);
+    hipLaunchKernelGGL(k<KIND>, dim3(nwg), dim3(256), 0, 0, out, 100, (long long*)nullptr);
+    long long* cyc; CHECK(hipHostMalloc(&cyc, 8)); *cyc = 0;
     CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(e0));
-    hipLaunchKernelGGL(k<KIND>, dim3(nwg), dim3(256), 0, 0, out, iters);
+    hipLaunchKernelGGL(k<KIND>, dim3(nwg), dim3(256), 0, 0, out, iters, cyc);
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
     // instructions per SIMD = wg_per_cu waves * iters * 8
     double inst_per_simd = (double)wg_per_cu * iters * 8 * 16;
-    printf("%-14s waves/SIMD=%d  %.3f ms  -> %.2f ns per wave-instr per SIMD (= %.2f cycles @2.4GHz)\n", name, wg_per_cu, ms,
-           ms * 1e6 / inst_per_simd, ms * 1e6 / inst_per_simd * 2.4);
+    printf("%-14s waves/SIMD=%d  %.3f ms  -> %.2f ns per wave-instr per SIMD; wave 0 ran %lld shader cycles = %.2f cycles per SIMD instr, clock %.2f GHz\n",
+           name, wg_per_cu, ms, ms * 1e6 / inst_per_simd, *cyc, (double)*cyc / inst_per_simd, *cyc / (ms * 1e6));
     return 0;
 }
 
