@@ -86,9 +86,8 @@ __global__ __launch_bounds__(64 * kWaves) void stft_rsmall_kernel(const SmallPar
     const float q0 = lu == 0 ? p.scale * 0.25f : q_in;
 
     // loads of group q+1 are issued before the FFT of group q (one group of register prefetch)
-    auto load_group = [&](int64_t qq, float2 (&dst)[8]) {
-        const int clip = static_cast<int>(qq / p.groups_per_clip);
-        const int fg = static_cast<int>(qq - static_cast<int64_t>(clip) * p.groups_per_clip) * G;
+    auto load_group = [&](int clip, int gi, float2 (&dst)[8]) {
+        const int fg = gi * G;
         const float* const xclip = p.x + static_cast<int64_t>(clip) * p.clip_stride + 2 * lane;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -98,17 +97,22 @@ __global__ __launch_bounds__(64 * kWaves) void stft_rsmall_kernel(const SmallPar
             for (int k = 0; k < R; ++k) dst[g * R + k] = *reinterpret_cast<const float2*>(src + 128 * k);
         }
     };
+    // (clip, group) of the run's first group by one division; after that they advance incrementally (a 64-bit
+    // division is ~200 scalar instructions, and the scalar unit is shared by the CU)
+    int clip = static_cast<int>(q / p.groups_per_clip);
+    int gi = static_cast<int>(q - static_cast<int64_t>(clip) * p.groups_per_clip);
     float2 nxt[8];
-    if (q < q_end) load_group(q, nxt);
+    if (q < q_end) load_group(clip, gi, nxt);
 
     for (; q < q_end; ++q) {
-        const int clip = static_cast<int>(q / p.groups_per_clip);
-        const int fg = static_cast<int>(q - static_cast<int64_t>(clip) * p.groups_per_clip) * G;
+        const int fg = gi * G;
+        const int clip_n = gi + 1 == p.groups_per_clip ? clip + 1 : clip, gi_n = gi + 1 == p.groups_per_clip ? 0 : gi + 1;
+        const bool more = q + 1 < q_end;                               // the run's last group fetches itself again
 
         float2 a[8];
 #pragma unroll
         for (int v = 0; v < 8; ++v) a[v] = nxt[v];
-        if (q + 1 < q_end) load_group(q + 1, nxt);
+        load_group(more ? clip_n : clip, more ? gi_n : gi, nxt);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             if (DETREND) {
@@ -176,6 +180,8 @@ __global__ __launch_bounds__(64 * kWaves) void stft_rsmall_kernel(const SmallPar
             orow[M / 2] = pq;
         }
         wave_lds_fence();
+        clip = clip_n;
+        gi = gi_n;
     }
 }
 
