@@ -80,5 +80,26 @@ def build(force=False, verbose=False):
     return LIB
 
 
+C_CLIENT_SRC = os.path.join(ROOT, "examples", "c_client.c")
+C_CLIENT = os.path.join(ROOT, "examples", "c_client")
+
+
+def build_c_client(force=False):
+    """examples/c_client: a plain C99 program against include/spectro.h -- proves the header is C-clean and the
+    library links without Python, torch or HIP headers on the caller's side (gcc only)."""
+    lib = build()
+    if not force and os.path.exists(C_CLIENT) and os.path.getmtime(C_CLIENT) >= max(os.path.getmtime(C_CLIENT_SRC), os.path.getmtime(lib)):
+        return C_CLIENT
+    cmd = ["gcc", "-O2", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), C_CLIENT_SRC,
+           "-L", LIBDIR, "-lspectro", "-lm", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,$ORIGIN/../spectrogram-generator_amd/lib",
+           "-o", C_CLIENT]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        print(r.stdout)
+        raise RuntimeError("gcc failed on examples/c_client.c")
+    return C_CLIENT
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
+    build_c_client(force="--force" in sys.argv)

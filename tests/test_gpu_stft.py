@@ -434,3 +434,29 @@ def test_long_single_clip_indexing(sp):
     a, b = frame(1234), frame(1234 + 200 * period)
     np.testing.assert_array_equal(a, b)
     dev.free()
+
+
+def test_c_client_matches_python_path_and_oracle(tmp_path):
+    """The plain-C caller (examples/c_client.c) of the ABI on the reference call's arguments: the Python shim's
+    result (same plan, same kernel; the two window tables may differ by an ulp of libm's cos) and the oracle's."""
+    import importlib.util
+    import os
+    import subprocess
+    from conftest import PKG
+    import spectro
+    spec = importlib.util.spec_from_file_location("spectro_build", os.path.join(PKG, "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    exe = mod.build_c_client()
+    rng = np.random.default_rng(31)
+    for n, nperseg, fs in [(48000, 1024, 48000.0), (16000, 512, 16000.0), (30000, 250, 500.0)]:
+        x = (rng.standard_normal(n) * 0.3).astype(np.float32)
+        fin, fout = tmp_path / "x.f32", tmp_path / "s.f32"
+        x.tofile(fin)
+        r = subprocess.run([exe, str(fin), str(n), repr(fs), str(nperseg), str(fout)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        f, t, s = spectro.spectrogram(x, fs=fs, nperseg=nperseg, scaling="density", mode="psd")
+        got = np.fromfile(fout, dtype=np.float32).reshape(len(t), len(f)).T
+        assert_spec_close(got, s, tol_frame=2e-6, tol_norm=1e-6, time_axis=-1)
+        fo, to, so = orc.spectrogram(x, fs=fs, nperseg=nperseg)
+        assert_spec_close(got, so, time_axis=-1)

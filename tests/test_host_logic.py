@@ -328,3 +328,20 @@ def test_jet_lut_matches_matplotlib():
     _capi.check(_capi.lib().sg_jet_lut(lut.ctypes.data_as(C.POINTER(C.c_uint8))))
     ref = (colormaps["jet"](np.arange(256)) * 255).astype(np.uint8)
     np.testing.assert_array_equal(lut, ref)          # same arithmetic as matplotlib's lookup table builder
+
+
+def test_c_client_builds_and_fails_loudly_without_a_gpu():
+    """The ABI from plain C (examples/c_client.c, gcc -std=c99 -Werror): compiles against include/spectro.h, links
+    libspectro.so without Python, and on a machine with no GPU exits with the library's own message (no fallback)."""
+    import importlib.util
+    import subprocess
+    from conftest import PKG
+    spec = importlib.util.spec_from_file_location("spectro_build", os.path.join(PKG, "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    exe = mod.build_c_client()
+    r = subprocess.run([exe, "--probe"], capture_output=True, text=True, timeout=120)
+    assert "libspectro ABI version" in r.stdout
+    assert r.returncode in (0, 3)
+    if r.returncode == 3:
+        assert "sg_init" in r.stderr and "no HIP device" in r.stderr
