@@ -25,7 +25,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=f
 # (tools/ubench/valu_rate.hip: 2.2 ns vs 1.2 ns per wave-instruction per SIMD), so SLP packing only adds
 # register-pair shuffles (v_pk_mov/v_mov) -- keep the scalar forms.
 EXTRA = {"stft_r8x3.hip": (["-fno-slp-vectorize"] if not os.environ.get("SG_SLP") else []) + os.environ.get("SG_R8_DEFS", "").split(),
-         "stft_rsmall.hip": ["-fno-slp-vectorize"], "stft_rbig.hip": ["-fno-slp-vectorize"] + os.environ.get("SG_RBIG_DEFS", "").split(), "stft_mel_fused.hip": ["-fno-slp-vectorize"] + os.environ.get("SG_FUSED_DEFS", "").split()}
+         "stft_rsmall.hip": ["-fno-slp-vectorize"] + os.environ.get("SG_RSMALL_DEFS", "").split(), "stft_rbig.hip": ["-fno-slp-vectorize"] + os.environ.get("SG_RBIG_DEFS", "").split(), "stft_mel_fused.hip": ["-fno-slp-vectorize"] + os.environ.get("SG_FUSED_DEFS", "").split()}
 
 
 def hipcc():

@@ -17,6 +17,10 @@
 #include <cmath>
 #include <cstdlib>
 
+#ifndef SG_FUSED_PRIO
+#define SG_FUSED_PRIO 1         // wave priority rises along a frame and stays high through the mel phase; 0 = off
+#endif
+
 namespace sg {
 namespace {
 
@@ -130,6 +134,7 @@ __global__ __launch_bounds__(256) void stft1024_mel_kernel(const FusedParams p) 
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) { a[k].x *= w[k].x; a[k].y *= w[k].y; }
+            if (SG_FUSED_PRIO) __builtin_amdgcn_s_setprio(0);
             radix8(a);
 #pragma unroll
             for (int r = 1; r < 8; ++r) a[r] = cmul(a[r], t1[r - 1]);
@@ -139,6 +144,7 @@ __global__ __launch_bounds__(256) void stft1024_mel_kernel(const FusedParams p) 
 #pragma unroll
             for (int b = 0; b < 8; ++b) a[b] = lds_get(x1r + b * kS1);
             wave_lds_fence();
+            if (SG_FUSED_PRIO) __builtin_amdgcn_s_setprio(1);
             radix8(a);
 #pragma unroll
             for (int s = 1; s < 8; ++s) a[s] = cmul(a[s], t2[s - 1]);
@@ -148,6 +154,7 @@ __global__ __launch_bounds__(256) void stft1024_mel_kernel(const FusedParams p) 
 #pragma unroll
             for (int j = 0; j < 8; ++j) a[j] = lds_get(x2r + j * kS2);
             wave_lds_fence();
+            if (SG_FUSED_PRIO) __builtin_amdgcn_s_setprio(2);
             radix8(a);
 #pragma unroll
             for (int t = 4; t < 8; ++t) lds_put(x3w + 64 * t, a[t]);
@@ -169,6 +176,7 @@ __global__ __launch_bounds__(256) void stft1024_mel_kernel(const FusedParams p) 
             if (lane == 0) trow[256] = fmaf(a[4].x, a[4].x, a[4].y * a[4].y) * (q_in * 4.0f);
             wave_lds_fence();
         }
+        if (SG_FUSED_PRIO) __builtin_amdgcn_s_setprio(3);
         __syncthreads();                                              // tile complete
 
         // ---------------- phase 2: mel contraction on the matrix cores ----------------

@@ -25,6 +25,9 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifndef SG_R8_PRIO
+#define SG_R8_PRIO 4          // wave priority along a frame: 4 = rising (0 pass 1, 1 pass 2, 2 pass 3, 3 split+stores+prefetch); 0 = off
+#endif
 #ifndef SG_R8_PF2
 #define SG_R8_PF2 0           // 1: sliding-window variants fetch two frames ahead (measured slower: 94.3 vs 90.0 us)
 #endif
@@ -169,6 +172,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
 
         // the spectrum of the frame held in a[] -> row orow (or one band sum), then orow advances
         auto process = [&](float2 (&a)[8]) {
+            if (SG_R8_PRIO == 5) __builtin_amdgcn_s_setprio(0);
             if (DETREND) {   // A3: subtract the frame mean (scipy:2191, detrend type 'constant')
                 float s = 0.f;
 #pragma unroll
@@ -180,6 +184,8 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
 #pragma unroll
             for (int k = 0; k < 8; ++k) { a[k].x *= w[k].x; a[k].y *= w[k].y; }   // A4 window
 
+            if (SG_R8_PRIO == 3) __builtin_amdgcn_s_setprio(3);
+            if (SG_R8_PRIO == 4 || SG_R8_PRIO == 6) __builtin_amdgcn_s_setprio(0);
             // ---- pass 1: DFT over a (stride-64 elements), twiddle w512^(lane*r)
             radix8(a);
 #pragma unroll
@@ -191,6 +197,8 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
             for (int b = 0; b < 8; ++b) a[b] = lds_get(x1r + b * kS1);
             wave_lds_fence();
 
+            if (SG_R8_PRIO == 3) __builtin_amdgcn_s_setprio(2);
+            if (SG_R8_PRIO == 4 || SG_R8_PRIO == 5) __builtin_amdgcn_s_setprio(1);
             // ---- pass 2: lane = j0 + 8r, DFT over b, twiddle w64^(j0*s)
             radix8(a);
 #pragma unroll
@@ -202,6 +210,9 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
             for (int j = 0; j < 8; ++j) a[j] = lds_get(x2r + j * kS2);
             wave_lds_fence();
 
+            if (SG_R8_PRIO == 3) __builtin_amdgcn_s_setprio(1);
+            if (SG_R8_PRIO == 4 || SG_R8_PRIO == 5) __builtin_amdgcn_s_setprio(2);
+            if (SG_R8_PRIO == 6) __builtin_amdgcn_s_setprio(3);
             // ---- pass 3: lane = r + 8s, DFT over j0 -> Z[lane + 64t]
             radix8(a);
             // Split pass pairs k = lane + 64m (m = 0..3, still in registers a[0..3]) with 512-k = Z[(64-lane) + 64(7-m)],
@@ -212,6 +223,8 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
             wave_lds_fence();
 
             // ---- split pass + |X|^2 epilogue (A5 tail + A6) ----------------------
+            if (SG_R8_PRIO == 1 || SG_R8_PRIO == 4 || SG_R8_PRIO == 5) __builtin_amdgcn_s_setprio(3);
+            if (SG_R8_PRIO == 2 || SG_R8_PRIO == 3) __builtin_amdgcn_s_setprio(0);
             float band = 0.f;
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
@@ -256,6 +269,8 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
             } else {
                 orow += kBins;
             }
+            if (SG_R8_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+            if (SG_R8_PRIO == 2) __builtin_amdgcn_s_setprio(3);
             wave_lds_fence();    // next frame's exchange-1 writes stay behind these reads
         };
 

@@ -27,6 +27,9 @@ using namespace wavefft;
 constexpr int kS1 = 72, kS2 = 66;
 // waves per workgroup (the LDS tables are shared by the workgroup): T = 4 -> one workgroup of 12 waves per CU
 // (43 KiB of tables + 12 x 4.5 KiB, 142 VGPRs = 3 waves/SIMD); T = 2 -> two workgroups of 8 (21 + 36 KiB each)
+#ifndef SG_RBIG_PRIO
+#define SG_RBIG_PRIO 1          // wave priority rises along a frame (pass 1 -> stores), as in stft_r8x3; 0 = off
+#endif
 #ifndef SG_RBIG4_OCC
 #define SG_RBIG4_OCC 3            // waves per SIMD the T = 4 kernel is compiled for
 #endif
@@ -165,6 +168,7 @@ __global__ __launch_bounds__(64 * WavesFor<T>::value, T == 4 ? SG_RBIG4_OCC : 4)
                 d[a0][a1].x *= w.x; d[a0][a1].y *= w.y;
             }
 
+        if (SG_RBIG_PRIO) __builtin_amdgcn_s_setprio(0);
         // ---- pass 1: R-point DFT over a = a0 + T*a1 --------------------------------------------------------
 #pragma unroll
         for (int a0 = 0; a0 < T; ++a0) {
@@ -198,6 +202,7 @@ __global__ __launch_bounds__(64 * WavesFor<T>::value, T == 4 ? SG_RBIG4_OCC : 4)
             wave_lds_fence();
         }
 
+        if (SG_RBIG_PRIO) __builtin_amdgcn_s_setprio(1);
         // ---- pass 2 ----------------------------------------------------------------------------------------------
 #pragma unroll
         for (int q = 0; q < T; ++q) {
@@ -221,12 +226,14 @@ __global__ __launch_bounds__(64 * WavesFor<T>::value, T == 4 ? SG_RBIG4_OCC : 4)
             wave_lds_fence();
         }
 
+        if (SG_RBIG_PRIO) __builtin_amdgcn_s_setprio(2);
         // ---- pass 3: d[q3][t] = Z[lane + 64*(q3 + T*t)] ---------------------------------------------------
         if (kLate) load_frame(clip_p, f_p, nxt, kPf == 1 ? 3 : 1);      // the rest follows as the split pass frees registers
 #pragma unroll
         for (int q3 = 0; q3 < T; ++q3) x_radix8(e[q3]);
 #define SG_Z(c) e[(c) % T][(c) / T]                          // Z[lane + 64*c]
 
+        if (SG_RBIG_PRIO) __builtin_amdgcn_s_setprio(3);
         // ---- split pass + epilogue: lower blocks c (registers) pair with upper blocks R-1-c (and element 0 of
         //      block R-c) of the mirrored lane; four blocks per trip through the slab ------------------------------
 #pragma unroll

@@ -15,6 +15,10 @@
 #include <cmath>
 #include <cstdlib>
 
+#ifndef SG_RSMALL_PRIO
+#define SG_RSMALL_PRIO 1        // wave priority rises along a group of frames (pass 1 -> stores), as in stft_r8x3; 0 = off
+#endif
+
 namespace sg {
 namespace {
 
@@ -113,6 +117,7 @@ __global__ __launch_bounds__(64 * kWaves) void stft_rsmall_kernel(const SmallPar
 #pragma unroll
         for (int v = 0; v < 8; ++v) a[v] = nxt[v];
         load_group(more ? clip_n : clip, more ? gi_n : gi, nxt);
+        if (SG_RSMALL_PRIO) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             if (DETREND) {
@@ -136,6 +141,7 @@ __global__ __launch_bounds__(64 * kWaves) void stft_rsmall_kernel(const SmallPar
         for (int b = 0; b < 8; ++b) a[b] = lds_get(x1r + b * kS1);
         wave_lds_fence();
 
+        if (SG_RSMALL_PRIO) __builtin_amdgcn_s_setprio(1);
         radix8(a);
 #pragma unroll
         for (int s = 1; s < 8; ++s) a[s] = cmul(a[s], t2[s - 1]);
@@ -146,12 +152,14 @@ __global__ __launch_bounds__(64 * kWaves) void stft_rsmall_kernel(const SmallPar
         for (int j = 0; j < 8; ++j) a[j] = lds_get(x2r + j * kS2);
         wave_lds_fence();
 
+        if (SG_RSMALL_PRIO) __builtin_amdgcn_s_setprio(2);
         radix8(a);
 #pragma unroll
         for (int t = 4; t < 8; ++t) lds_put(x3w + L * t, a[t]);
         if (lu == 0) lds_put(buf + g3 * RS + M, a[0]);                 // Z_g[M] := Z_g[0]
         wave_lds_fence();
 
+        if (SG_RSMALL_PRIO) __builtin_amdgcn_s_setprio(3);
         const int f = fg + g3;
         const bool live = f < p.n_frames;
         float* const orow = p.out + static_cast<int64_t>(clip) * p.out_clip_stride + static_cast<int64_t>(min(f, p.n_frames - 1)) * NB;
