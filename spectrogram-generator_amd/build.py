@@ -24,7 +24,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=f
 # Per-file extras.  stft_r8x3 is VALU-bound: gfx950 issues v_pk_*_f32 at half the rate of the plain ops
 # (tools/ubench/valu_rate.hip: 2.2 ns vs 1.2 ns per wave-instruction per SIMD), so SLP packing only adds
 # register-pair shuffles (v_pk_mov/v_mov) -- keep the scalar forms.
-EXTRA = {"stft_r8x3.hip": (["-fno-slp-vectorize"] if not os.environ.get("SG_SLP") else []) + os.environ.get("SG_R8_DEFS", "").split(),
+EXTRA = {"mel.hip": os.environ.get("SG_MEL_DEFS", "").split(),
+         "stft_r8x3.hip": (["-fno-slp-vectorize"] if not os.environ.get("SG_SLP") else []) + os.environ.get("SG_R8_DEFS", "").split(),
          "stft_rsmall.hip": ["-fno-slp-vectorize"] + os.environ.get("SG_RSMALL_DEFS", "").split(), "stft_rbig.hip": ["-fno-slp-vectorize"] + os.environ.get("SG_RBIG_DEFS", "").split(), "stft_mel_fused.hip": ["-fno-slp-vectorize"] + os.environ.get("SG_FUSED_DEFS", "").split()}
 
 

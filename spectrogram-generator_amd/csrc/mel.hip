@@ -11,6 +11,11 @@
 
 #include <cmath>
 
+// SG_MEL_ABL (tuning aid, wrong results): 1 weights not loaded, 2 no MFMA
+#ifndef SG_MEL_ABL
+#define SG_MEL_ABL 0
+#endif
+
 namespace sg {
 namespace {
 
@@ -25,7 +30,13 @@ struct MelParams {
     int k_pad;               // n_bins rounded up to a multiple of 16
     float* out;              // [n_frames][n_mels]
     int k_lo[kMaxTiles], k_hi[kMaxTiles];   // per mel tile: k range (multiples of 16, hi exclusive) with non-zero weights
+    // LDSW kernels: the non-zero (mel tile, k block) pairs, 1 KiB of weights each, live in LDS for the whole kernel
+    int n_pairs;
+    int pair_base[kMaxTiles];               // tile t's pairs are pair_base[t] + (k0 - k_lo[t]) / 16
+    int64_t n_tiles16;                      // ceil(n_frames / 16)
+    int64_t n_waves;                        // persistent grid: waves striding over the 16-frame tiles
 };
+constexpr int kMaxPairs = 63;               // 63 KiB of LDS
 
 // One wavefront per 16 consecutive frames.  The contraction index is consumed 16 at a time: lane (i = l&15,
 // kq = l>>4) loads the spectrum row f0+i at k = 16j + 4kq .. +3 ONCE and, for every mel tile whose triangles
@@ -33,38 +44,76 @@ struct MelParams {
 // multiplies element e of both.  Any bijection between (step, kq) and k is a valid order for the sum as long as
 // A and B agree, so no cross-lane shuffle is needed.  All NT tile accumulators stay live, so the spectrum is read
 // from HBM exactly once.  Accumulator map: col = l&15 (mel), row = 4*(l>>4) + reg (frame).
-template <int NT>
+// LDSW: persistent workgroups keep the block-sparse weights in LDS (loaded once per workgroup) and stride over the
+// 16-frame tiles; otherwise (a bank too dense for LDS) one wave per tile with the weights read through L1/L2 -- those
+// reads were as many bytes as the spectrum itself and cost 30 of 113 us on the cfg3 batch.
+template <int NT, bool LDSW>
 __global__ __launch_bounds__(256) void mel_kernel(const MelParams p) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];           // [pair][lane][4]
     const int lane = threadIdx.x & 63;
-    const int64_t tile = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
-    const int64_t f0 = tile * 16;
-    if (f0 >= p.n_frames) return;
     const int i = lane & 15, kq = lane >> 4;
+    if (LDSW) {
+        for (int idx = threadIdx.x; idx < p.n_pairs * 64; idx += 256) {
+            const int pair = idx >> 6, l = idx & 63;
+            int t = 0;
+#pragma unroll
+            for (int tt = 1; tt < NT; ++tt) if (pair >= p.pair_base[tt]) t = tt;
+            const int k0 = p.k_lo[t] + 16 * (pair - p.pair_base[t]);
+            *reinterpret_cast<f32x4*>(wl + idx * 4) =
+                *reinterpret_cast<const f32x4*>(p.wt + static_cast<int64_t>(16 * t + (l & 15)) * p.k_pad + k0 + 4 * (l >> 4));
+        }
+        __syncthreads();
+    }
+    const float* const wrow = p.wt + static_cast<int64_t>(i) * p.k_pad + 4 * kq;
+    const int k_last = p.n_bins - 1 - 4 * kq;            // last valid index relative to arow
+    const int64_t wave0 = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    for (int64_t tile = wave0; tile < p.n_tiles16; tile += p.n_waves) {
+    const int64_t f0 = tile * 16;
     int64_t fa = f0 + i;
     if (fa >= p.n_frames) fa = p.n_frames - 1;           // clamp: rows past the end are computed but not stored
     const float* const arow = p.spec + fa * p.n_bins + 4 * kq;
-    const float* const wrow = p.wt + static_cast<int64_t>(i) * p.k_pad + 4 * kq;
-    const int k_last = p.n_bins - 1 - 4 * kq;            // last valid index relative to arow
     f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int k_full = (p.n_bins - 16) & ~15;            // blocks below this never touch the row end
-    for (int k0 = 0; k0 < p.k_pad; k0 += 16) {
-        f32x4 a;
-        if (k0 < k_full) {
-            a = f32x4{arow[k0], arow[k0 + 1], arow[k0 + 2], arow[k0 + 3]};     // rows are only 4-byte aligned (n_bins odd)
-        } else {   // tail of the row: clamp (the padded weights are zero there)
-            a = f32x4{arow[min(k0, k_last)], arow[min(k0 + 1, k_last)], arow[min(k0 + 2, k_last)], arow[min(k0 + 3, k_last)]};
+    auto load_a = [&](int k0) -> f32x4 {
+        if (k0 < k_full) return f32x4{arow[k0], arow[k0 + 1], arow[k0 + 2], arow[k0 + 3]};   // rows are only 4-byte aligned (n_bins odd)
+        // tail of the row (and the look-ahead past it): clamp -- the padded weights are zero there
+        return f32x4{arow[min(k0, k_last)], arow[min(k0 + 1, k_last)], arow[min(k0 + 2, k_last)], arow[min(k0 + 3, k_last)]};
+    };
+    // The spectrum is streamed kAhead k-blocks ahead of the MFMAs (two register sets).  Measured on the cfg3 batch with
+    // the weights in LDS: look-ahead 1 / 2 / 4 / 8 blocks = 84 / 78 / 104 / 160 us (deeper queues of 4-byte gathers
+    // thrash the L1) -- 2 it is; the one-wave-per-tile form already has 8 waves/SIMD of loads in flight and uses none.
+    constexpr int kAhead = LDSW ? 2 : 1;
+    f32x4 nxt[kAhead];
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) nxt[u] = LDSW ? load_a(16 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kg = 0; kg < p.k_pad; kg += 16 * kAhead) {
+        f32x4 cur[kAhead];
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) cur[u] = LDSW ? nxt[u] : load_a(kg + 16 * u);
+        if (LDSW) {
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) nxt[u] = load_a(kg + 16 * (kAhead + u));
         }
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (k0 >= p.k_lo[t] && k0 < p.k_hi[t]) {      // wave-uniform: block sparsity of the triangular bank
-                const f32x4 b = *reinterpret_cast<const f32x4*>(wrow + static_cast<int64_t>(16 * t) * p.k_pad + k0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc[t], 0, 0, 0);
+        for (int u = 0; u < kAhead; ++u) {
+            const int k0 = kg + 16 * u;
+            if (k0 >= p.k_pad) break;
+            const f32x4 a = cur[u];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (k0 >= p.k_lo[t] && k0 < p.k_hi[t]) {      // wave-uniform: block sparsity of the triangular bank
+                    const f32x4 b = (SG_MEL_ABL & 1) ? f32x4{0.5f, 0.25f, 0.125f, 1.f}
+                                    : LDSW ? *reinterpret_cast<const f32x4*>(wl + ((p.pair_base[t] + ((k0 - p.k_lo[t]) >> 4)) * 64 + lane) * 4)
+                                           : *reinterpret_cast<const f32x4*>(wrow + static_cast<int64_t>(16 * t) * p.k_pad + k0);
+                    if (SG_MEL_ABL & 2) { acc[t] += a * b; continue; }
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc[t], 0, 0, 0);
+                }
             }
         }
     }
@@ -83,11 +132,13 @@ __global__ __launch_bounds__(256) void mel_kernel(const MelParams p) {
             }
         }
     }
+    }
 }
 
 template <int NT>
-void launch_mel(const MelParams& p, unsigned grid, hipStream_t s) {
-    hipLaunchKernelGGL(mel_kernel<NT>, dim3(grid), dim3(256), 0, s, p);
+void launch_mel(const MelParams& p, unsigned grid, bool ldsw, hipStream_t s) {
+    if (ldsw) hipLaunchKernelGGL((mel_kernel<NT, true>), dim3(grid), dim3(256), static_cast<size_t>(p.n_pairs) * 1024, s, p);
+    else hipLaunchKernelGGL((mel_kernel<NT, false>), dim3(grid), dim3(256), 0, s, p);
 }
 
 }  // namespace
@@ -162,16 +213,31 @@ int sg_mel(const float* spec_dev, int64_t n_frames, int n_bins, const float* wei
         if (p.k_hi[t] > p.k_pad) p.k_hi[t] = p.k_pad;
     }
     const int64_t tiles = (n_frames + 15) / 16;
-    const unsigned grid = static_cast<unsigned>((tiles + 3) / 4);
+    p.n_tiles16 = tiles;
+    int n_pairs = 0;
+    for (int t = 0; t < p.n_tiles; ++t) { p.pair_base[t] = n_pairs; n_pairs += (p.k_hi[t] - p.k_lo[t]) / 16; }
+    p.n_pairs = n_pairs;
+    const bool ldsw = n_pairs >= 1 && n_pairs <= kMaxPairs;
+    unsigned grid = static_cast<unsigned>((tiles + 3) / 4);
+    if (ldsw) {                                          // persistent: as many workgroups as fit the CUs' LDS (160 KiB each)
+        int dev = 0, n_cu = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        int per_cu = (160 * 1024) / (n_pairs * 1024);
+        if (per_cu > 8) per_cu = 8;
+        if (per_cu < 1) per_cu = 1;
+        const unsigned cap = static_cast<unsigned>(n_cu) * per_cu;
+        if (grid > cap) grid = cap;
+    }
+    p.n_waves = static_cast<int64_t>(grid) * 4;
     switch (p.n_tiles) {
-        case 1: launch_mel<1>(p, grid, s); break;
-        case 2: launch_mel<2>(p, grid, s); break;
-        case 3: launch_mel<3>(p, grid, s); break;
-        case 4: launch_mel<4>(p, grid, s); break;
-        case 5: launch_mel<5>(p, grid, s); break;
-        case 6: launch_mel<6>(p, grid, s); break;
-        case 7: launch_mel<7>(p, grid, s); break;
-        default: launch_mel<8>(p, grid, s); break;
+        case 1: launch_mel<1>(p, grid, ldsw, s); break;
+        case 2: launch_mel<2>(p, grid, ldsw, s); break;
+        case 3: launch_mel<3>(p, grid, ldsw, s); break;
+        case 4: launch_mel<4>(p, grid, ldsw, s); break;
+        case 5: launch_mel<5>(p, grid, ldsw, s); break;
+        case 6: launch_mel<6>(p, grid, ldsw, s); break;
+        case 7: launch_mel<7>(p, grid, ldsw, s); break;
+        default: launch_mel<8>(p, grid, ldsw, s); break;
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "mel launch");

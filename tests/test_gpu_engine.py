@@ -317,3 +317,26 @@ def test_epilogue_abi_random_shapes(dtype):
         assert np.allclose(got, want, rtol=1e-6 if dtype == np.float32 else 1e-13, atol=0)
         for b_ in (buf, img, mm, sums):
             b_.free()
+
+
+@pytest.mark.parametrize("nfft,n_mels,rows", [(1024, 80, 70003), (1024, 128, 1000), (256, 8, 333), (512, 40, 4099),
+                                              (4096, 64, 257), (1000, 23, 100)])
+def test_mel_abi_shapes(nfft, n_mels, rows):
+    """sg_mel on synthetic spectra: more 16-frame tiles than persistent waves (70 003 rows), 1 and 8 mel tiles, banks whose
+    weights fit LDS and banks that do not (nfft 4096), ragged row counts, odd nfft -- against a float64 product."""
+    from spectro import _capi
+    from spectro.mel import MelBank
+    _capi.ensure_device()
+    rng = np.random.default_rng(nfft + n_mels)
+    nb = nfft // 2 + 1
+    spec = (rng.random((rows, nb), dtype=np.float32) ** 4) * np.linspace(2.0, 0.01, nb, dtype=np.float32)
+    bank = MelBank(nfft, 48000.0, n_mels)
+    d_in, d_out = _capi.DeviceBuffer(spec.nbytes), _capi.DeviceBuffer(rows * n_mels * 4)
+    d_in.upload(spec)
+    ref = spec.astype(np.float64) @ bank.weights.astype(np.float32).astype(np.float64)
+    for dense in (False, True):
+        got = np.zeros((rows, n_mels), np.float32)
+        bank.apply_ptr(d_in.ptr, rows, d_out.ptr, False, dense)
+        d_out.download(got); _capi.stream_sync()
+        assert np.allclose(got, ref, rtol=2e-5, atol=2e-6 * ref.max())
+    d_in.free(); d_out.free(); bank.close()
