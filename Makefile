@@ -1,0 +1,29 @@
+# Builds libspectro.so (hipcc, gfx950) and the plain-C client without Python.  `python spectrogram-generator_amd/build.py`
+# does the same (that is what the tests and __graft_entry__.build() call); keep the flag lists in step with it.
+HIPCC   ?= /opt/rocm/bin/hipcc
+CC      ?= gcc
+PKG     := spectrogram-generator_amd
+CSRC    := $(PKG)/csrc
+LIBDIR  := $(PKG)/lib
+SOURCES := spectro_api stft_r8x3 stft_rsmall stft_rbig stft_stockham stft_bluestein epilogue mel stft_mel_fused
+OBJS    := $(SOURCES:%=$(LIBDIR)/%.o)
+HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -fno-gpu-rdc -Wall -Wno-unused-function -Wno-unused-result
+# register-FFT kernels: gfx950 issues v_pk_*_f32 at half rate, so no SLP packing (see build.py)
+NOSLP   := stft_r8x3 stft_rsmall stft_rbig stft_mel_fused
+
+all: $(LIBDIR)/libspectro.so examples/c_client
+
+$(LIBDIR)/%.o: $(CSRC)/%.hip $(CSRC)/fft_wave.h $(CSRC)/spectro_internal.h include/spectro.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) $(if $(filter $*,$(NOSLP)),-fno-slp-vectorize) -I include -I $(CSRC) -c $< -o $@
+
+$(LIBDIR)/libspectro.so: $(OBJS)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(OBJS) -o $@
+
+examples/c_client: examples/c_client.c include/spectro.h $(LIBDIR)/libspectro.so
+	$(CC) -O2 -std=c99 -Wall -Wextra -Werror -I include $< -L $(LIBDIR) -lspectro -lm -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -o $@
+
+clean:
+	rm -f $(LIBDIR)/*.o $(LIBDIR)/libspectro.so examples/c_client
+
+.PHONY: all clean
