@@ -43,7 +43,10 @@ constexpr int kBins = 513;
 constexpr int kS1 = 72;         // LDS stride (elements) of exchange 1: [b][l2]
 constexpr int kS2 = 66;         // LDS stride of exchange 2: [j0][l3]
 constexpr int kSlab = 8 * kS1;  // 576 complex = 4608 B per wave
-constexpr int kWavesPerWg = 4;
+#ifndef SG_R8_WPW
+#define SG_R8_WPW 4
+#endif
+constexpr int kWavesPerWg = SG_R8_WPW;
 #ifndef SG_TW_LDS
 // 0: twiddles in VGPRs (4 waves/SIMD); 1: in a workgroup-shared LDS table (5 waves/SIMD).  Sustained A/B on MI355X
 // (bench.py, 400 steps): VGPR 96-97 us vs LDS 99.5 us per launch -- the 18 extra ds_read_b64 per frame cost more
