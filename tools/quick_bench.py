@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Quick device timing of sg_stft on the cfg2 shape (no torch): python tools/quick_bench.py [n_clips] [hop] [kernel|-] [nfft]"""
+"""Quick device timing of sg_stft on the cfg2 shape (no torch): python tools/quick_bench.py [n_clips] [hop] [kernel|-] [nfft] [n_samples]"""
 import os
 import sys
 import time
@@ -13,7 +13,7 @@ from spectro.windows import get_window  # noqa: E402
 n_clips = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 hop = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 kernel = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] != "-" else None
-N, n = 480000, (int(sys.argv[4]) if len(sys.argv) > 4 else 1024)
+N, n = (int(sys.argv[5]) if len(sys.argv) > 5 else 480000), (int(sys.argv[4]) if len(sys.argv) > 4 else 1024)
 _capi.ensure_device()
 print(_capi.device_info())
 x = (np.random.default_rng(1234).standard_normal((n_clips, N)) * 0.1).astype(np.float32)
