@@ -11,11 +11,6 @@
 
 #include <cmath>
 
-// SG_MEL_ABL (tuning aid, wrong results): 1 weights not loaded, 2 no MFMA
-#ifndef SG_MEL_ABL
-#define SG_MEL_ABL 0
-#endif
-
 namespace sg {
 namespace {
 
@@ -105,10 +100,8 @@ __global__ __launch_bounds__(256) void mel_kernel(const MelParams p) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 if (k0 >= p.k_lo[t] && k0 < p.k_hi[t]) {      // wave-uniform: block sparsity of the triangular bank
-                    const f32x4 b = (SG_MEL_ABL & 1) ? f32x4{0.5f, 0.25f, 0.125f, 1.f}
-                                    : LDSW ? *reinterpret_cast<const f32x4*>(wl + ((p.pair_base[t] + ((k0 - p.k_lo[t]) >> 4)) * 64 + lane) * 4)
-                                           : *reinterpret_cast<const f32x4*>(wrow + static_cast<int64_t>(16 * t) * p.k_pad + k0);
-                    if (SG_MEL_ABL & 2) { acc[t] += a * b; continue; }
+                    const f32x4 b = LDSW ? *reinterpret_cast<const f32x4*>(wl + ((p.pair_base[t] + ((k0 - p.k_lo[t]) >> 4)) * 64 + lane) * 4)
+                                         : *reinterpret_cast<const f32x4*>(wrow + static_cast<int64_t>(16 * t) * p.k_pad + k0);
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc[t], 0, 0, 0);

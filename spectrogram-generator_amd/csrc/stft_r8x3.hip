@@ -26,10 +26,7 @@
 #include <type_traits>
 
 #ifndef SG_R8_PRIO
-#define SG_R8_PRIO 4          // wave priority along a frame: 4 = rising (0 pass 1, 1 pass 2, 2 pass 3, 3 split+stores+prefetch); 0 = off
-#endif
-#ifndef SG_R8_PF2
-#define SG_R8_PF2 0           // 1: sliding-window variants fetch two frames ahead (measured slower: 94.3 vs 90.0 us)
+#define SG_R8_PRIO 1          // wave priority rises along a frame (0 pass 1, 1 pass 2, 2 pass 3, 3 split + stores + next prefetch); 0 = off
 #endif
 
 namespace sg {
@@ -175,7 +172,6 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
 
         // the spectrum of the frame held in a[] -> row orow (or one band sum), then orow advances
         auto process = [&](float2 (&a)[8]) {
-            if (SG_R8_PRIO == 5) __builtin_amdgcn_s_setprio(0);
             if (DETREND) {   // A3: subtract the frame mean (scipy:2191, detrend type 'constant')
                 float s = 0.f;
 #pragma unroll
@@ -187,8 +183,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
 #pragma unroll
             for (int k = 0; k < 8; ++k) { a[k].x *= w[k].x; a[k].y *= w[k].y; }   // A4 window
 
-            if (SG_R8_PRIO == 3) __builtin_amdgcn_s_setprio(3);
-            if (SG_R8_PRIO == 4 || SG_R8_PRIO == 6) __builtin_amdgcn_s_setprio(0);
+            if (SG_R8_PRIO) __builtin_amdgcn_s_setprio(0);
             // ---- pass 1: DFT over a (stride-64 elements), twiddle w512^(lane*r)
             radix8(a);
 #pragma unroll
@@ -200,8 +195,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
             for (int b = 0; b < 8; ++b) a[b] = lds_get(x1r + b * kS1);
             wave_lds_fence();
 
-            if (SG_R8_PRIO == 3) __builtin_amdgcn_s_setprio(2);
-            if (SG_R8_PRIO == 4 || SG_R8_PRIO == 5) __builtin_amdgcn_s_setprio(1);
+            if (SG_R8_PRIO) __builtin_amdgcn_s_setprio(1);
             // ---- pass 2: lane = j0 + 8r, DFT over b, twiddle w64^(j0*s)
             radix8(a);
 #pragma unroll
@@ -213,9 +207,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
             for (int j = 0; j < 8; ++j) a[j] = lds_get(x2r + j * kS2);
             wave_lds_fence();
 
-            if (SG_R8_PRIO == 3) __builtin_amdgcn_s_setprio(1);
-            if (SG_R8_PRIO == 4 || SG_R8_PRIO == 5) __builtin_amdgcn_s_setprio(2);
-            if (SG_R8_PRIO == 6) __builtin_amdgcn_s_setprio(3);
+            if (SG_R8_PRIO) __builtin_amdgcn_s_setprio(2);
             // ---- pass 3: lane = r + 8s, DFT over j0 -> Z[lane + 64t]
             radix8(a);
             // Split pass pairs k = lane + 64m (m = 0..3, still in registers a[0..3]) with 512-k = Z[(64-lane) + 64(7-m)],
@@ -226,8 +218,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
             wave_lds_fence();
 
             // ---- split pass + |X|^2 epilogue (A5 tail + A6) ----------------------
-            if (SG_R8_PRIO == 1 || SG_R8_PRIO == 4 || SG_R8_PRIO == 5) __builtin_amdgcn_s_setprio(3);
-            if (SG_R8_PRIO == 2 || SG_R8_PRIO == 3) __builtin_amdgcn_s_setprio(0);
+            if (SG_R8_PRIO) __builtin_amdgcn_s_setprio(3);
             float band = 0.f;
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
@@ -272,59 +263,28 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
             } else {
                 orow += kBins;
             }
-            if (SG_R8_PRIO == 1) __builtin_amdgcn_s_setprio(0);
-            if (SG_R8_PRIO == 2) __builtin_amdgcn_s_setprio(3);
             wave_lds_fence();    // next frame's exchange-1 writes stay behind these reads
         };
 
-        if (H > 0 && SG_R8_PF2) {
-            // Sliding window, fetched two frames ahead: the H new registers of frame f+2 are requested at the top of
-            // frame f and join the window at the end of frame f+1, so a request has two frame times to return and the
-            // stores of two frames may be in flight behind it (vmcnt retires in order).  Two register sets alternate.
-            constexpr int HH = H > 0 ? H : 1;
-            float2 na[HH], nb[HH];
-            auto fetch = [&](float2 (&dst)[HH], const TIn* at) {
+        // (fetching two frames ahead, so that two frames of stores may be in flight behind a request, measured slower:
+        //  94.3 vs 90.0 us)
+        for (int f = f0; f < f1; ++f) {
+            float2 a[8];
 #pragma unroll
-                for (int i = 0; i < HH; ++i) dst[i] = load_pair<TIn, ALIGNED>(at + 128 * (8 - HH + i));
-            };
-            auto step = [&](float2 (&use)[HH], float2 (&fill)[HH], int f) {
-                float2 a[8];
+            for (int k = 0; k < 8; ++k) a[k] = raw[k];
+            src += p.hop;
+            if (f + 1 < f1) {      // prefetch frame f+1 (wave-uniform branch)
+                if (H > 0) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) a[k] = raw[k];
-                src += p.hop;                                              // frame f+1
-                if (f + 2 < f1) fetch(fill, src + p.hop);
-                process(a);
+                    for (int k = 0; k + H < 8; ++k) raw[k] = raw[k + H];
 #pragma unroll
-                for (int k = 0; k + HH < 8; ++k) raw[k] = raw[k + HH];
+                    for (int k = (H > 0 ? 8 - H : 0); k < 8; ++k) raw[k] = load_pair<TIn, ALIGNED>(src + 128 * k);
+                } else {
 #pragma unroll
-                for (int i = 0; i < HH; ++i) raw[8 - HH + i] = use[i];
-            };
-            if (f0 + 1 < f1) fetch(na, src + p.hop);
-            int f = f0;
-            for (; f + 1 < f1; f += 2) {
-                step(na, nb, f);
-                step(nb, na, f + 1);
-            }
-            if (f < f1) step(na, nb, f);
-        } else {
-            for (int f = f0; f < f1; ++f) {
-                float2 a[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) a[k] = raw[k];
-                src += p.hop;
-                if (f + 1 < f1) {      // prefetch frame f+1 (wave-uniform branch)
-                    if (H > 0) {
-#pragma unroll
-                        for (int k = 0; k + H < 8; ++k) raw[k] = raw[k + H];
-#pragma unroll
-                        for (int k = (H > 0 ? 8 - H : 0); k < 8; ++k) raw[k] = load_pair<TIn, ALIGNED>(src + 128 * k);
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) raw[k] = load_pair<TIn, ALIGNED>(src + 128 * k);
-                    }
+                    for (int k = 0; k < 8; ++k) raw[k] = load_pair<TIn, ALIGNED>(src + 128 * k);
                 }
-                process(a);
             }
+            process(a);
         }
     }
     }

@@ -33,9 +33,6 @@ constexpr int kS1 = 72, kS2 = 66;
 #ifndef SG_RBIG4_OCC
 #define SG_RBIG4_OCC 3            // waves per SIMD the T = 4 kernel is compiled for
 #endif
-#ifndef SG_RBIG4_PF
-#define SG_RBIG4_PF 0             // T = 4 prefetch: 0 none, 1 half + quarter + quarter (late), 2 four late quarters, 3 whole frame at the top
-#endif
 template <int T> struct WavesFor { static constexpr int value = T == 4 ? 4 * SG_RBIG4_OCC : 8; };
 constexpr int kSlabElems = 8 * kS1;                          // one 8-register exchange group (576 float2)
 
@@ -51,15 +48,6 @@ struct BigParams {
     const float2* tw;         // [(R-1) + 7 + R/2][64]
     float scale;
 };
-
-// SG_RBIG_ABL (tuning aid, wrong results): 1 no exchange traffic, 2 no table reads, 4 no stores, 8 no butterflies
-#ifndef SG_RBIG_ABL
-#define SG_RBIG_ABL 0
-#endif
-__device__ __forceinline__ void x_put(float2* p, float2 v) { if (!(SG_RBIG_ABL & 1)) lds_put(p, v); }
-__device__ __forceinline__ float2 x_get(const float2* p, float2 keep) { if (SG_RBIG_ABL & 1) return keep; return lds_get(p); }
-__device__ __forceinline__ float2 t_get(const float2* p) { if (SG_RBIG_ABL & 2) return make_float2(0.75f, 0.5f); return lds_get(p); }
-template <int N> __device__ __forceinline__ void x_radix8(float2 (&v)[N]) { if (!(SG_RBIG_ABL & 8)) radix8(v); }
 
 template <int T> __device__ __forceinline__ void radix_t(float2 (&v)[T]);
 template <> __device__ __forceinline__ void radix_t<2>(float2 (&v)[2]) {
@@ -116,38 +104,38 @@ __global__ __launch_bounds__(64 * WavesFor<T>::value, T == 4 ? SG_RBIG4_OCC : 4)
     const float q0 = lane == 0 ? p.scale * 0.25f : q_in;
 
     // T = 2 fetches the samples of frame g+1 at the top of frame g (+32 VGPRs throughout).  T = 4 has no registers to
-    // spare; its late-prefetch forms (SG_RBIG4_PF 1/2: fetch as the split pass frees registers; 3 at 2 waves/SIMD)
-    // all measured slower than plain loads at 3 waves/SIMD (1.78 ms vs 1.83-2.26 ms at hop 64) and stay off.
-    constexpr int kPf = T == 4 ? SG_RBIG4_PF : 3;
-    constexpr bool kLate = kPf == 1 || kPf == 2;
-    // quarters: bit (a1 >> 1) of the mask selects registers d[*][a1]
-    auto load_frame = [&](int clip, int f, float2 (&dst)[T][8], int quarters) {
+    // spare and loads at the top of the frame; fetching late, as the split pass frees registers, or whole frames ahead at
+    // 2 waves/SIMD, measured slower (1.83-2.26 ms against 1.78 ms per 64-clip batch at hop 64).
+    constexpr bool kPrefetch = T == 2;
+    auto load_frame = [&](int clip, int f, float2 (&dst)[T][8]) {
         const float* const src = p.x + static_cast<int64_t>(clip) * p.clip_stride + static_cast<int64_t>(f) * p.hop + 2 * lane;
 #pragma unroll
         for (int a0 = 0; a0 < T; ++a0)
 #pragma unroll
-            for (int a1 = 0; a1 < 8; ++a1)
-                if ((quarters >> (a1 >> 1)) & 1) dst[a0][a1] = *reinterpret_cast<const float2*>(src + 128 * (a0 + T * a1));
+            for (int a1 = 0; a1 < 8; ++a1) dst[a0][a1] = *reinterpret_cast<const float2*>(src + 128 * (a0 + T * a1));
     };
     // (clip, frame) of the run's first frame by one division; after that they advance incrementally
     int clip = static_cast<int>(g / p.n_frames);
     int f = static_cast<int>(g - static_cast<int64_t>(clip) * p.n_frames);
-    float2 nxt[T][8];
-    if (kPf != 0 && g < g_end) load_frame(clip, f, nxt, 15);
+    float2 nxt[kPrefetch ? T : 1][8];
+    if (kPrefetch && g < g_end) load_frame(clip, f, reinterpret_cast<float2 (&)[T][8]>(nxt));
 
     for (; g < g_end; ++g) {
         float* const orow = p.out + static_cast<int64_t>(clip) * p.out_clip_stride + static_cast<int64_t>(f) * NB;
         const int clip_n = f + 1 == p.n_frames ? clip + 1 : clip, f_n = f + 1 == p.n_frames ? 0 : f + 1;
-        // the run's last frame fetches itself again: an unconditional fetch keeps the old registers out of the loop's live set
-        const int clip_p = g + 1 < g_end ? clip_n : clip, f_p = g + 1 < g_end ? f_n : f;
 
         float2 d[T][8];
+        if (kPrefetch) {
 #pragma unroll
-        for (int a0 = 0; a0 < T; ++a0)
+            for (int a0 = 0; a0 < T; ++a0)
 #pragma unroll
-            for (int a1 = 0; a1 < 8; ++a1) d[a0][a1] = nxt[a0][a1];
-        if (kPf == 0) load_frame(clip, f, d, 15);
-        if (kPf == 3) load_frame(clip_p, f_p, nxt, 15);
+                for (int a1 = 0; a1 < 8; ++a1) d[a0][a1] = nxt[kPrefetch ? a0 : 0][a1];
+            // the run's last frame fetches itself again: an unconditional fetch keeps the old registers out of the loop's live set
+            const bool more = g + 1 < g_end;
+            load_frame(more ? clip_n : clip, more ? f_n : f, reinterpret_cast<float2 (&)[T][8]>(nxt));
+        } else {
+            load_frame(clip, f, d);
+        }
         if (DETREND) {
             float s = 0.f;
 #pragma unroll
@@ -164,7 +152,7 @@ __global__ __launch_bounds__(64 * WavesFor<T>::value, T == 4 ? SG_RBIG4_OCC : 4)
         for (int a0 = 0; a0 < T; ++a0)
 #pragma unroll
             for (int a1 = 0; a1 < 8; ++a1) {
-                const float2 w = t_get(wtab + 64 * (a0 + T * a1));
+                const float2 w = lds_get(wtab + 64 * (a0 + T * a1));
                 d[a0][a1].x *= w.x; d[a0][a1].y *= w.y;
             }
 
@@ -172,7 +160,7 @@ __global__ __launch_bounds__(64 * WavesFor<T>::value, T == 4 ? SG_RBIG4_OCC : 4)
         // ---- pass 1: R-point DFT over a = a0 + T*a1 --------------------------------------------------------
 #pragma unroll
         for (int a0 = 0; a0 < T; ++a0) {
-            x_radix8(d[a0]);                                 // over a1 -> r1
+            radix8(d[a0]);                                 // over a1 -> r1
             if (a0 > 0) {
 #pragma unroll
                 for (int r1 = 1; r1 < 8; ++r1) d[a0][r1] = cmul(d[a0][r1], const_tw<R>(a0 * r1));
@@ -191,14 +179,14 @@ __global__ __launch_bounds__(64 * WavesFor<T>::value, T == 4 ? SG_RBIG4_OCC : 4)
         for (int q = 0; q < T; ++q)
 #pragma unroll
             for (int r1 = 0; r1 < 8; ++r1)
-                if (q + r1 > 0) d[q][r1] = cmul(d[q][r1], t_get(t1 + 64 * (r1 + 8 * q - 1)));
+                if (q + r1 > 0) d[q][r1] = cmul(d[q][r1], lds_get(t1 + 64 * (r1 + 8 * q - 1)));
 #pragma unroll
         for (int q = 0; q < T; ++q) {                        // exchange 1, one group of 8 at a time through the slab
 #pragma unroll
-            for (int r1 = 0; r1 < 8; ++r1) x_put(x1w + 8 * r1, d[q][r1]);
+            for (int r1 = 0; r1 < 8; ++r1) lds_put(x1w + 8 * r1, d[q][r1]);
             wave_lds_fence();
 #pragma unroll
-            for (int b = 0; b < 8; ++b) d[q][b] = x_get(x1r + b * kS1, d[q][b]);
+            for (int b = 0; b < 8; ++b) d[q][b] = lds_get(x1r + b * kS1);
             wave_lds_fence();
         }
 
@@ -206,9 +194,9 @@ __global__ __launch_bounds__(64 * WavesFor<T>::value, T == 4 ? SG_RBIG4_OCC : 4)
         // ---- pass 2 ----------------------------------------------------------------------------------------------
 #pragma unroll
         for (int q = 0; q < T; ++q) {
-            x_radix8(d[q]);
+            radix8(d[q]);
 #pragma unroll
-            for (int s = 1; s < 8; ++s) d[q][s] = cmul(d[q][s], t_get(t2 + 64 * (s - 1)));
+            for (int s = 1; s < 8; ++s) d[q][s] = cmul(d[q][s], lds_get(t2 + 64 * (s - 1)));
         }
         float2 e[T][8];                                      // pass-3 operands: e[q3][j]
 #pragma unroll
@@ -218,19 +206,18 @@ __global__ __launch_bounds__(64 * WavesFor<T>::value, T == 4 ? SG_RBIG4_OCC : 4)
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
                     const int uu = 8 * q + R * s;            // + r1 (= hi) < 8 never carries into the next 64
-                    if (uu / 64 == q3) x_put(x2w + (uu % 64), d[q][s]);
+                    if (uu / 64 == q3) lds_put(x2w + (uu % 64), d[q][s]);
                 }
             wave_lds_fence();
 #pragma unroll
-            for (int j = 0; j < 8; ++j) e[q3][j] = x_get(x2r + j * kS2, d[(j + q3) % T][(q3 + 3 * j) % 8]);
+            for (int j = 0; j < 8; ++j) e[q3][j] = lds_get(x2r + j * kS2);
             wave_lds_fence();
         }
 
         if (SG_RBIG_PRIO) __builtin_amdgcn_s_setprio(2);
         // ---- pass 3: d[q3][t] = Z[lane + 64*(q3 + T*t)] ---------------------------------------------------
-        if (kLate) load_frame(clip_p, f_p, nxt, kPf == 1 ? 3 : 1);      // the rest follows as the split pass frees registers
 #pragma unroll
-        for (int q3 = 0; q3 < T; ++q3) x_radix8(e[q3]);
+        for (int q3 = 0; q3 < T; ++q3) radix8(e[q3]);
 #define SG_Z(c) e[(c) % T][(c) / T]                          // Z[lane + 64*c]
 
         if (SG_RBIG_PRIO) __builtin_amdgcn_s_setprio(3);
@@ -239,15 +226,15 @@ __global__ __launch_bounds__(64 * WavesFor<T>::value, T == 4 ? SG_RBIG4_OCC : 4)
 #pragma unroll
         for (int i = 0; i < R / 8; ++i) {
 #pragma unroll
-            for (int sl = 0; sl < 4; ++sl) x_put(x3w + 64 * sl, SG_Z(R - 4 * i - 4 + sl));
-            if (lane == 0) x_put(buf + 256, i == 0 ? SG_Z(0) : SG_Z(R - 4 * i));   // i = 0: Z[M] := Z[0]
+            for (int sl = 0; sl < 4; ++sl) lds_put(x3w + 64 * sl, SG_Z(R - 4 * i - 4 + sl));
+            if (lane == 0) lds_put(buf + 256, i == 0 ? SG_Z(0) : SG_Z(R - 4 * i));   // i = 0: Z[M] := Z[0]
             wave_lds_fence();
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) {
                 const int c = 4 * i + cc;
                 const float2 A = SG_Z(c);
-                const float2 B = x_get(x3b - 64 * cc, SG_Z(R - 1 - c));
-                const float2 cs = t_get(t3 + 64 * c);
+                const float2 B = lds_get(x3b - 64 * cc);
+                const float2 cs = lds_get(t3 + 64 * c);
                 const float2 S = make_float2(A.x + B.x, A.y - B.y);
                 const float2 D = make_float2(A.x - B.x, A.y + B.y);
                 const float2 Tt = make_float2(fmaf(cs.y, D.x, -cs.x * D.y), fmaf(cs.x, D.x, cs.y * D.y));
@@ -257,14 +244,10 @@ __global__ __launch_bounds__(64 * WavesFor<T>::value, T == 4 ? SG_RBIG4_OCC : 4)
                 float pm = fmaf(Xm.x, Xm.x, Xm.y * Xm.y) * qq;
                 if (MODE == 1) { pk = sqrtf(pk); pm = sqrtf(pm); }
                 const int k = lane + 64 * c;
-                if (!(SG_RBIG_ABL & 4) || pk == 1234.5f) {
-                    orow[k] = pk;
-                    orow[M - k] = pm;
-                }
+                orow[k] = pk;
+                orow[M - k] = pm;
             }
             wave_lds_fence();
-            if (kPf == 1 && i < 2) load_frame(clip_p, f_p, nxt, 4 << i);      // each trip frees 8 registers of e
-            if (kPf == 2 && i < 3) load_frame(clip_p, f_p, nxt, 2 << i);
         }
         clip = clip_n;
         f = f_n;
