@@ -177,17 +177,28 @@ __global__ __launch_bounds__(kThreads) void slice_kernel(const T* spec, int64_t 
         for (int k = lane; k < width; k += 64) dst[f * width + k] = spec[f * n_bins + k_lo + k];
 }
 
-// one wavefront per frame
+// one wavefront per 4 frames (four rows of loads in flight per wave step)
 template <typename T>
 __global__ __launch_bounds__(kThreads) void band_sum_kernel(const T* spec, int64_t n_frames, int n_bins, int k_lo, int k_hi, T* band) {
+    constexpr int R = 4;
     const int lane = threadIdx.x & 63;
     const int64_t wave = static_cast<int64_t>(blockIdx.x) * (kThreads / 64) + (threadIdx.x >> 6);
     const int64_t n_waves = static_cast<int64_t>(gridDim.x) * (kThreads / 64);
-    for (int64_t f = wave; f < n_frames; f += n_waves) {
-        T s = T(0);
-        for (int k = k_lo + lane; k <= k_hi; k += 64) s += spec[f * n_bins + k];
-        s = wave_add(s);
-        if (lane == 0) band[f] = s;
+    for (int64_t f0 = wave * R; f0 < n_frames; f0 += n_waves * R) {
+        const int nr = n_frames - f0 < R ? static_cast<int>(n_frames - f0) : R;
+        const T* const rows = spec + f0 * n_bins;
+        T s[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) s[r] = T(0);
+        for (int k = k_lo + lane; k <= k_hi; k += 64) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) s[r] += r < nr ? rows[static_cast<int64_t>(r) * n_bins + k] : T(0);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const T t = wave_add(s[r]);
+            if (lane == 0 && r < nr) band[f0 + r] = t;
+        }
     }
 }
 
@@ -457,7 +468,7 @@ int sg_band_sum(const void* spec_dev, int dtype, int64_t n_frames, int n_bins, i
     if (int rc = check_band(n_frames, n_bins, k_lo, k_hi)) return rc;
     if (n_frames == 0) return SG_OK;
     auto s = static_cast<hipStream_t>(stream);
-    const unsigned g = grid_for(n_frames * 64);
+    const unsigned g = grid_for((n_frames + 3) / 4 * 64);
     if (dtype == SG_F32)
         hipLaunchKernelGGL(band_sum_kernel<float>, dim3(g), dim3(kThreads), 0, s, static_cast<const float*>(spec_dev), n_frames,
                            n_bins, k_lo, k_hi, static_cast<float*>(band_dev));

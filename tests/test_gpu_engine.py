@@ -297,6 +297,10 @@ def test_epilogue_abi_random_shapes(dtype):
             _capi.check(L.sg_minmax(spec, code, rows, nb, k_lo, k_hi, C.c_void_p(mm.ptr), None))
             got = mm.download(np.zeros(2, dtype)); _capi.stream_sync()
             assert got[0] == ref.min() and got[1] == ref.max()
+            bsum = np.zeros(rows, dtype)
+            _capi.check(L.sg_band_sum(spec, code, rows, nb, k_lo, k_hi, C.c_void_p(img.ptr), None))
+            img.download(bsum); _capi.stream_sync()
+            assert np.allclose(bsum, ref.astype(np.float64).sum(axis=1), rtol=2e-6 if dtype == np.float32 else 1e-13, atol=0)
             out = np.zeros((rows, w), dtype)
             _capi.check(L.sg_slice_bins(spec, code, rows, nb, k_lo, k_hi, C.c_void_p(img.ptr), None))
             img.download(out); _capi.stream_sync()

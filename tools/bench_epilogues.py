@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Time the A8-A13 epilogue kernels on the cfg2-size spectrum (119 808 x 513 f32 = 246 MB) against their HBM bytes."""
+"""Time the A8-A13 epilogue kernels on the cfg2-size spectrum (119 808 x 513 f32 = 246 MB) against their HBM bytes.
+Three spectra rotate so that the 256 MiB Infinity Cache cannot serve the reads."""
 import ctypes as C, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "spectrogram-generator_amd"))
@@ -7,9 +8,22 @@ from spectro import _capi
 _capi.ensure_device()
 L = _capi.lib()
 rows, nb = 119808, 513
-spec = _capi.DeviceBuffer(rows * nb * 4)
 host = (np.random.default_rng(0).random((rows, nb), dtype=np.float32) + 1e-3)
-spec.upload(host); _capi.stream_sync()
+specs = [_capi.DeviceBuffer(rows * nb * 4) for _ in range(3)]
+for b_ in specs:
+    b_.upload(host)
+_capi.stream_sync()
+turn = [0]
+
+
+class _Rot:
+    @property
+    def ptr(self):
+        turn[0] += 1
+        return specs[turn[0] % 3].ptr
+
+
+spec = _Rot()
 img = _capi.DeviceBuffer(rows * nb * 4)
 band = _capi.DeviceBuffer(rows * 4)
 feat = _capi.DeviceBuffer(rows * 8)
