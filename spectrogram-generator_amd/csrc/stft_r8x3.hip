@@ -148,9 +148,16 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
     float2* const x3w = buf + lane;                 // + 64*t
     const float2* const x3b = buf + (kM - lane);    // - 64*m
 
-    const float q_in = MODE == 0 ? p.scale * 0.5f : p.scale * 0.25f;     // interior bins (psd: doubled)
-    const float q_edge = p.scale * 0.25f;                                // bins 0 and 512
-    const float q0 = lane == 0 ? q_edge : q_in;
+    // |X|^2 * q: q = scale/2 for the interior bins of a one-sided PSD (doubled), scale/4 for bins 0 and 512 and for every
+    // bin of a magnitude spectrum.  sqrt(q_in) rides on the window registers (16 multiplies per wave instead of 8 per
+    // frame); what is left per frame is the factor 1/2 on lane 0's bins 0 and 512 of a PSD.
+    const float q_in = MODE == 0 ? p.scale * 0.5f : p.scale * 0.25f;
+    {
+        const float sq = sqrtf(q_in);
+#pragma unroll
+        for (int a = 0; a < 8; ++a) { w[a].x *= sq; w[a].y *= sq; }
+    }
+    const float r0 = (MODE == 0 && lane == 0) ? 0.5f : 1.0f;
 
     for (; chunk < n_chunks; chunk += p.n_waves) {
     int64_t g = p.run_len > 0 ? chunk * p.run_len : p.total_frames * lw / p.n_waves;
@@ -230,9 +237,9 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
                 const float2 T = make_float2(fmaf(cs.y, D.x, -cs.x * D.y), fmaf(cs.x, D.x, cs.y * D.y));   // i*W^k*D
                 const float2 Xk = csub(S, T), Xm = cadd(S, T);      // 2*X[k], 2*conj(X[512-k])
                 // (|S|^2 + |D|^2 -+ 2Re(S conj T) would save two ops but cancels catastrophically for weak bins)
-                const float q = m == 0 ? q0 : q_in;
-                float pk = fmaf(Xk.x, Xk.x, Xk.y * Xk.y) * q;
-                float pm = fmaf(Xm.x, Xm.x, Xm.y * Xm.y) * q;
+                float pk = fmaf(Xk.x, Xk.x, Xk.y * Xk.y);
+                float pm = fmaf(Xm.x, Xm.x, Xm.y * Xm.y);
+                if (MODE == 0 && m == 0) { pk *= r0; pm *= r0; }
                 if (MODE == 1) { pk = sqrtf(pk); pm = sqrtf(pm); }
                 const int k = lane + 64 * m;
                 if (BAND) {
@@ -246,7 +253,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
             {   // k = 256 pairs with itself: X[256] = conj(Z[256]); Z[256] is lane 0's a[4]
                 const float zx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a[4].x), 0));
                 const float zy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a[4].y), 0));
-                float pq = fmaf(zx, zx, zy * zy) * (q_in * 4.0f);
+                float pq = fmaf(zx, zx, zy * zy) * 4.0f;
                 if (MODE == 1) pq = sqrtf(pq);
                 if (BAND) {
                     band += (lane == 0 && 256 >= p.k_lo && 256 <= p.k_hi) ? pq : 0.f;
