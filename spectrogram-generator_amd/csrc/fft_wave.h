@@ -43,21 +43,22 @@ __device__ __forceinline__ float dpp_mov(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
 }
 
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_rows(float x) {     // rows outside ROW_MASK get 0
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROW_MASK, 0xf, false));
-}
-
 // Sum over the 64 lanes as a wave-uniform value (lands in an SGPR, so it can be a scalar operand of what follows).
 // DPP butterflies inside a row of 16, then row_bcast15 / row_bcast31 carry the row sums into row 3: 6 VALU + 1 readlane
-// (reading the four row sums with v_readlane and adding them cost twice that).
+// (reading the four row sums with v_readlane and adding them cost twice that).  The two row_bcast adds are written
+// out: with a row mask the instruction leaves the other rows untouched, which is the "+ 0" wanted there -- through
+// the update_dpp builtin the compiler materialises that zero with two extra moves per step.
 __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_mov<0xB1>(v);              // quad_perm [1,0,3,2]  (lane ^ 1)
     v += dpp_mov<0x4E>(v);              // quad_perm [2,3,0,1]  (lane ^ 2)
     v += dpp_mov<0x141>(v);             // row_half_mirror      (the other quad of each 8)
     v += dpp_mov<0x140>(v);             // row_mirror           (the other 8 of each 16): every lane holds its row's sum
-    v += dpp_rows<0x142, 0xA>(v);       // row_bcast15 into rows 1 and 3: r0+r1, r2+r3
-    v += dpp_rows<0x143, 0xC>(v);       // row_bcast31 into rows 2 and 3: row 3 = r0+r1+r2+r3
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"     // rows 1, 3: r0+r1, r2+r3
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"       // row 3: r0+r1+r2+r3
+                 "s_nop 0"
+                 : "+v"(v));
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 

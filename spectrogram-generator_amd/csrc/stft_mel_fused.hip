@@ -125,9 +125,9 @@ __global__ __launch_bounds__(256) void stft1024_mel_kernel(const FusedParams p) 
                 }
             }
             if (DETREND) {
-                float s = 0.f;
+                float s = a[0].x + a[0].y;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) s += a[k].x + a[k].y;
+                for (int k = 1; k < 8; ++k) s += a[k].x + a[k].y;
                 const float mean = wave_sum(s) * (1.0f / kN);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { a[k].x -= mean; a[k].y -= mean; }

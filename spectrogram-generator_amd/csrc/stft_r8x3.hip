@@ -180,9 +180,9 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
         // the spectrum of the frame held in a[] -> row orow (or one band sum), then orow advances
         auto process = [&](float2 (&a)[8]) {
             if (DETREND) {   // A3: subtract the frame mean (scipy:2191, detrend type 'constant')
-                float s = 0.f;
+                float s = a[0].x + a[0].y;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) s += a[k].x + a[k].y;
+                for (int k = 1; k < 8; ++k) s += a[k].x + a[k].y;
                 const float mean = wave_sum(s) * (1.0f / kN);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { a[k].x -= mean; a[k].y -= mean; }

@@ -137,11 +137,12 @@ __global__ __launch_bounds__(64 * WavesFor<T>::value, T == 4 ? SG_RBIG4_OCC : 4)
             load_frame(clip, f, d);
         }
         if (DETREND) {
-            float s = 0.f;
+            float s = d[0][0].x + d[0][0].y;
 #pragma unroll
             for (int a0 = 0; a0 < T; ++a0)
 #pragma unroll
-                for (int a1 = 0; a1 < 8; ++a1) s += d[a0][a1].x + d[a0][a1].y;
+                for (int a1 = 0; a1 < 8; ++a1)
+                    if (a0 + a1 > 0) s += d[a0][a1].x + d[a0][a1].y;
             const float mean = wave_sum(s) * (1.0f / (2 * M));
 #pragma unroll
             for (int a0 = 0; a0 < T; ++a0)

@@ -121,9 +121,9 @@ __global__ __launch_bounds__(64 * kWaves) void stft_rsmall_kernel(const SmallPar
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             if (DETREND) {
-                float s = 0.f;
+                float s = a[g * R].x + a[g * R].y;
 #pragma unroll
-                for (int k = 0; k < R; ++k) s += a[g * R + k].x + a[g * R + k].y;
+                for (int k = 1; k < R; ++k) s += a[g * R + k].x + a[g * R + k].y;
                 const float mean = wave_sum(s) * (1.0f / (2 * M));
 #pragma unroll
                 for (int k = 0; k < R; ++k) { a[g * R + k].x -= mean; a[g * R + k].y -= mean; }
