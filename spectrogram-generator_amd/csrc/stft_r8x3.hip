@@ -177,8 +177,8 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
 #pragma unroll
         for (int k = 0; k < 8; ++k) raw[k] = load_pair<TIn, ALIGNED>(src + 128 * k);
 
-        // the spectrum of the frame held in a[] -> row orow (or one band sum), then orow advances
-        auto process = [&](float2 (&a)[8]) {
+        // A3 + A4 on the frame held in a[] (reads only; the sample registers stay intact)
+        auto prep = [&](float2 (&a)[8]) {
             if (DETREND) {   // A3: subtract the frame mean (scipy:2191, detrend type 'constant')
                 float s = a[0].x + a[0].y;
 #pragma unroll
@@ -189,7 +189,9 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) { a[k].x *= w[k].x; a[k].y *= w[k].y; }   // A4 window
-
+        };
+        // the spectrum of the windowed frame in a[] -> row orow (or one band sum), then orow advances
+        auto process = [&](float2 (&a)[8]) {
             if (SG_R8_PRIO) __builtin_amdgcn_s_setprio(0);
             // ---- pass 1: DFT over a (stride-64 elements), twiddle w512^(lane*r)
             radix8(a);
@@ -221,7 +223,8 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
             // which sits in registers a[4..7] of lane 64-lane: only the upper half crosses lanes (4 LDS writes, not 8).
 #pragma unroll
             for (int t = 4; t < 8; ++t) lds_put(x3w + 64 * t, a[t]);
-            if (lane == 0) lds_put(buf + kM, a[0]);         // Z[512] := Z[0] closes the k <-> 512-k pairing
+            lds_put(buf + kM + lane, a[0]);                 // lane 0: Z[512] := Z[0] closes the k <-> 512-k pairing (the slab's
+                                                            // last 63 slots take the other lanes' copies: no exec-mask branch)
             wave_lds_fence();
 
             // ---- split pass + |X|^2 epilogue (A5 tail + A6) ----------------------
@@ -275,10 +278,13 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
 
         // (fetching two frames ahead, so that two frames of stores may be in flight behind a request, measured slower:
         //  94.3 vs 90.0 us)
+        // (rotating the sample window through its registers -- hop = 2 registers: unrolled by four, no moves -- saves the
+        //  six 64-bit moves per frame but needs 142 VGPRs: 83.6-84.7 us at 3 waves/SIMD against 84.3-85.1, not worth 4x the code)
         for (int f = f0; f < f1; ++f) {
             float2 a[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) a[k] = raw[k];
+            prep(a);
             src += p.hop;
             if (f + 1 < f1) {      // prefetch frame f+1 (wave-uniform branch)
                 if (H > 0) {
