@@ -79,6 +79,10 @@ int sg_host_unregister(void* host_ptr);
 int sg_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream);
 int sg_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);
 int sg_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes, void* stream); /* ranges may not overlap */
+/* `height` rows of `width_bytes`, row pitches in bytes (streaming: one call moves a [channels][n] chunk into / out of the
+ * per-channel device buffers); kind: 0 host->device, 1 device->host, 2 device->device */
+int sg_memcpy2d(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width_bytes, size_t height,
+                int kind, void* stream);
 int sg_memset(void* dst_dev, int value, size_t bytes, void* stream);
 int sg_stream_create(void** stream);
 int sg_stream_destroy(void* stream);

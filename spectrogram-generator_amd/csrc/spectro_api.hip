@@ -198,6 +198,15 @@ int sg_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes, void* stream
     if (bytes) SG_HIP(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
     return SG_OK;
 }
+int sg_memcpy2d(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width_bytes, size_t height, int kind,
+                void* stream) {
+    if (kind < 0 || kind > 2) { set_error("sg_memcpy2d: kind must be 0 (h2d), 1 (d2h) or 2 (d2d)"); return SG_ERR_ARG; }
+    if (width_bytes > dst_pitch || width_bytes > src_pitch) { set_error("sg_memcpy2d: width exceeds a pitch"); return SG_ERR_ARG; }
+    if (!width_bytes || !height) return SG_OK;
+    const hipMemcpyKind k = kind == 0 ? hipMemcpyHostToDevice : kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    SG_HIP(hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width_bytes, height, k, static_cast<hipStream_t>(stream)));
+    return SG_OK;
+}
 int sg_memset(void* dst_dev, int value, size_t bytes, void* stream) {
     if (bytes) SG_HIP(hipMemsetAsync(dst_dev, value, bytes, static_cast<hipStream_t>(stream)));
     return SG_OK;

@@ -2,9 +2,10 @@
 
 Not in the reference (it only ever calls the offline function); the contract is offline equivalence: the frames
 produced by feeding a signal in arbitrary chunks equal ``spectrogram`` of the whole signal, frame for frame.
-Per channel the device keeps the unconsumed tail (< nperseg + hop samples) in front of a staging buffer; every
-``feed`` appends the chunk (one H2D copy per call for all channels), runs ONE ``sg_stft`` launch over all channels
-on ``[tail | chunk]`` and slides the tail with a device-to-device copy.
+Per channel the device keeps a long staging row; a ``feed`` appends the chunk behind the unconsumed tail (ONE 2-D
+H2D copy for all channels), runs ONE ``sg_stft`` launch over all channels on ``[tail | chunk]``, fetches the new
+frames (one D2H copy) and merely advances the row's start offset.  Only when a row runs out of room is the tail moved
+back to its front (two 2-D device copies, once every ~``slack`` chunks): four driver calls per chunk instead of 26.
 """
 from __future__ import annotations
 
@@ -32,16 +33,23 @@ class StreamingSTFT:
                              _capi.SCALING[scaling], _capi.MODE[mode], code)
         self.n_bins = self.plan.n_bins
         self.max_chunk = int(max_chunk)
-        self._stride = (self.nperseg + self.hop + self.max_chunk + 1) & ~1   # samples per channel (even: keeps float2 loads aligned)
+        self._slack = 32                                # chunks appended between two slides of the tail
+        self._tail_max = (self.nperseg + self.hop + 1) & ~1
+        self._stride = (self._tail_max + (self._slack + 1) * self.max_chunk + 1) & ~1   # samples per channel row (even: float2 loads stay aligned)
         isz = self.dtype.itemsize
         self._buf = _capi.DeviceBuffer(self.n_channels * self._stride * isz)
-        self._tmp = _capi.DeviceBuffer(self.n_channels * (self.nperseg + self.hop) * isz)
-        max_frames = (self._stride - self.nperseg) // self.hop + 1
+        self._tmp = _capi.DeviceBuffer(self.n_channels * self._tail_max * isz)
+        max_frames = (self._tail_max + self.max_chunk - self.nperseg) // self.hop + 1
         self._out = _capi.DeviceBuffer(self.n_channels * max_frames * self.n_bins * isz)
         self._max_frames = max_frames
-        self._fill = 0                 # valid samples per channel currently in the buffer
-        self._consumed = 0             # samples dropped from the front so far (= absolute index of buffer start)
+        self._start = 0                # offset (samples, even) of the first unconsumed sample in every row
+        self._fill = 0                 # valid samples per channel behind _start
+        self._consumed = 0             # samples dropped from the front so far (= absolute index of _start)
         self.frames_emitted = 0
+
+    def _copy2d(self, dst, dst_pitch, src, src_pitch, width, kind):
+        import ctypes as C
+        _capi.check(_capi.lib().sg_memcpy2d(C.c_void_p(dst), dst_pitch, C.c_void_p(src), src_pitch, width, self.n_channels, kind, None))
 
     def feed(self, chunk):
         """``chunk``: ``[n_channels, n]`` (or 1-D for one channel).  Returns ``(t, S[channel, bin, frame])`` for the
@@ -54,31 +62,25 @@ class StreamingSTFT:
             parts = [self.feed(x[:, i:i + self.max_chunk]) for i in range(0, n, self.max_chunk)]
             return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts], axis=-1)
         isz = self.dtype.itemsize
-        lib = _capi.lib()
-        import ctypes as C
+        row = self._stride * isz
+        if self._start + self._fill + n > self._stride:        # out of room: move the tail to the front of the rows
+            if self._fill:                                     # (through a scratch buffer: the ranges may overlap)
+                self._copy2d(self._tmp.ptr, self._tail_max * isz, self._buf.ptr + self._start * isz, row, self._fill * isz, 2)
+                self._copy2d(self._buf.ptr, row, self._tmp.ptr, self._tail_max * isz, self._fill * isz, 2)
+            self._start = 0
         xh = np.ascontiguousarray(x, self.dtype)
-        keep = []
-        for c in range(self.n_channels):           # strided destination: one copy per channel row
-            if n:
-                keep.append(np.ascontiguousarray(xh[c]))
-                _capi.check(lib.sg_memcpy_h2d(C.c_void_p(self._buf.ptr + (c * self._stride + self._fill) * isz),
-                                              keep[-1].ctypes.data_as(C.c_void_p), n * isz, None))
+        if n:
+            self._copy2d(self._buf.ptr + (self._start + self._fill) * isz, row, xh.ctypes.data, n * isz, n * isz, 0)
         self._fill += n
         n_frames = self.plan.n_frames(self._fill)
         out = np.empty((self.n_channels, n_frames, self.n_bins), self.dtype)
         if n_frames:
-            self.plan.stft(self._buf.ptr, self._fill, self._stride, self.n_channels, self._out.ptr, n_frames * self.n_bins)
+            self.plan.stft(self._buf.ptr + self._start * isz, self._fill, self._stride, self.n_channels, self._out.ptr,
+                           n_frames * self.n_bins)
             self._out.download(out)
             used = n_frames * self.hop             # samples fully consumed; the rest is the next frame's head
-            rest = self._fill - used
-            if rest:
-                for c in range(self.n_channels):   # slide through a scratch buffer (ranges overlap in place)
-                    _capi.check(lib.sg_memcpy_d2d(C.c_void_p(self._tmp.ptr + c * (self.nperseg + self.hop) * isz),
-                                                  C.c_void_p(self._buf.ptr + (c * self._stride + used) * isz), rest * isz, None))
-                for c in range(self.n_channels):
-                    _capi.check(lib.sg_memcpy_d2d(C.c_void_p(self._buf.ptr + c * self._stride * isz),
-                                                  C.c_void_p(self._tmp.ptr + c * (self.nperseg + self.hop) * isz), rest * isz, None))
-            self._fill = rest
+            self._start += used                    # (an even hop keeps the rows 8-byte aligned for the register kernels)
+            self._fill -= used
             self._consumed += used
         _capi.stream_sync()
         first = self.frames_emitted

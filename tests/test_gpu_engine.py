@@ -199,6 +199,30 @@ def test_streaming_equals_offline(nperseg, hop, n_ch, fs):
     st.close()
 
 
+@pytest.mark.parametrize("nperseg,hop,max_chunk", [(256, 64, 300), (256, 37, 256), (1024, 256, 1000), (100, 100, 64)])
+def test_streaming_many_small_chunks(nperseg, hop, max_chunk):
+    """The staging rows only advance an offset per chunk and move the tail back to the front when they run out of room
+    (every ~32 chunks): hundreds of small ragged chunks, even and odd hops, still equal the offline call."""
+    import spectro
+    from spectro.stream import StreamingSTFT
+    rng = np.random.default_rng(hop)
+    total = 60000
+    x = (rng.standard_normal((2, total)) * 0.3 + 0.1).astype(np.float32)
+    st = StreamingSTFT(2, 8000.0, nperseg, hop, window="hann", max_chunk=max_chunk)
+    pos, ts, outs = 0, [], []
+    while pos < total:
+        n = min(int(rng.integers(0, max_chunk + 1)), total - pos)
+        t, s = st.feed(x[:, pos:pos + n])
+        ts.append(t); outs.append(s)
+        pos += n
+    t_all, s_all = np.concatenate(ts), np.concatenate(outs, axis=-1)
+    f, t_ref, s_ref = spectro.spectrogram(x, fs=8000.0, nperseg=nperseg, window="hann", noverlap=nperseg - hop)
+    assert s_all.shape == s_ref.shape and len(ts) > 100
+    np.testing.assert_array_equal(t_all, t_ref)
+    assert_spec_close(s_all, s_ref, time_axis=-1)
+    st.close()
+
+
 @pytest.mark.parametrize("hop,n_mels,detrend", [(256, 80, "constant"), (896, 40, "constant"), (130, 128, False)])
 def test_fused_stft_mel(hop, n_mels, detrend):
     """cfg3 fused kernel (sg_stft_mel): equals mel(oracle PSD) and the unfused sg_stft + sg_mel path, incl. a frame
