@@ -143,9 +143,12 @@ int sg_stft_band_power(const sg_plan* plan, const void* x_dev, int64_t n_samples
                        void* band_out_dev, int64_t out_clip_stride, void* stream);
 
 /* ---- epilogues over a frame-major spectrum (A8..A13) ------------------ */
-/* `dtype` (sg_dtype) is the element type of every spectrum / image / band buffer below. */
+/* `dtype` (sg_dtype) is the element type of every spectrum / image / band buffer below.
+ * The reductions (sg_minmax, sg_normalise_image, sg_band_totals) run in two stages through a 256 KiB scratch that the
+ * library keeps per (device, stream) from its first use until it is unloaded; calls on one stream are ordered, calls on
+ * different streams do not share it. */
 /* mm_dev[0] = min, mm_dev[1] = max over rows [0,n_frames) x bins [k_lo,k_hi] of spec (row stride n_bins).
- * mm_dev: 2 elements of dtype (used as scratch while the kernel runs). */
+ * mm_dev: 2 elements of dtype. */
 int sg_minmax(const void* spec_dev, int dtype, int64_t n_frames, int n_bins, int k_lo, int k_hi,
               void* mm_dev, void* stream);
 /*
