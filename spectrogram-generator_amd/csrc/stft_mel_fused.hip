@@ -79,7 +79,13 @@ __global__ __launch_bounds__(256) void stft1024_mel_kernel(const FusedParams p) 
     float2* const x2r = buf + lane;
     float2* const x3w = buf + lane;
     const float2* const x3b = buf + (kM - lane);
-    const float q_in = p.scale * 0.5f, q0 = lane == 0 ? p.scale * 0.25f : q_in;
+    // sqrt of the PSD scale rides on the window registers (stft_r8x3.hip)
+    {
+        const float sq = sqrtf(p.scale * 0.5f);
+#pragma unroll
+        for (int a = 0; a < 8; ++a) { w[a].x *= sq; w[a].y *= sq; }
+    }
+    const float r0 = lane == 0 ? 0.5f : 1.0f;
     const int mi = lane & 15, kq = lane >> 4;
 
     for (; tid_tile < tile_end; ++tid_tile) {
@@ -169,11 +175,12 @@ __global__ __launch_bounds__(256) void stft1024_mel_kernel(const FusedParams p) 
                 const float2 D = make_float2(A.x - B.x, A.y + B.y);
                 const float2 T = make_float2(fmaf(cs.y, D.x, -cs.x * D.y), fmaf(cs.x, D.x, cs.y * D.y));
                 const float2 Xk = csub(S, T), Xm = cadd(S, T);
-                const float q = m == 0 ? q0 : q_in;
-                trow[lane + 64 * m] = fmaf(Xk.x, Xk.x, Xk.y * Xk.y) * q;
-                trow[kM - lane - 64 * m] = fmaf(Xm.x, Xm.x, Xm.y * Xm.y) * q;
+                float pk = fmaf(Xk.x, Xk.x, Xk.y * Xk.y), pm = fmaf(Xm.x, Xm.x, Xm.y * Xm.y);
+                if (m == 0) { pk *= r0; pm *= r0; }
+                trow[lane + 64 * m] = pk;
+                trow[kM - lane - 64 * m] = pm;
             }
-            if (lane == 0) trow[256] = fmaf(a[4].x, a[4].x, a[4].y * a[4].y) * (q_in * 4.0f);
+            if (lane == 0) trow[256] = fmaf(a[4].x, a[4].x, a[4].y * a[4].y) * 4.0f;
             wave_lds_fence();
         }
         if (SG_FUSED_PRIO) __builtin_amdgcn_s_setprio(3);

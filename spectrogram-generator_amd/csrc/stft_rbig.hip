@@ -79,7 +79,12 @@ __global__ __launch_bounds__(64 * WavesFor<T>::value, T == 4 ? SG_RBIG4_OCC : 4)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float2* const buf = lds + kTabs + wave * kSlab;
 
-    for (int i = threadIdx.x; i < M; i += 64 * kWaves) lds[i] = p.win2[i];
+    // sqrt of the PSD scale rides on the window table (stft_r8x3.hip); per frame only the 1/2 on bins 0 and M is left
+    const float q_in = MODE == 0 ? p.scale * 0.5f : p.scale * 0.25f;
+    {
+        const float sq = sqrtf(q_in);
+        for (int i = threadIdx.x; i < M; i += 64 * kWaves) { const float2 wv = p.win2[i]; lds[i] = make_float2(wv.x * sq, wv.y * sq); }
+    }
     for (int i = threadIdx.x; i < kTabs - M; i += 64 * kWaves) lds[M + i] = p.tw[i];
     __syncthreads();
 
@@ -100,8 +105,7 @@ __global__ __launch_bounds__(64 * WavesFor<T>::value, T == 4 ? SG_RBIG4_OCC : 4)
     float2* const x3w = buf + lane;                          // + 64*slot, 4 upper blocks per group
     const float2* const x3b = buf + (256 - lane);            // - 64*(c - 4i)
 
-    const float q_in = MODE == 0 ? p.scale * 0.5f : p.scale * 0.25f;
-    const float q0 = lane == 0 ? p.scale * 0.25f : q_in;
+    const float r0 = (MODE == 0 && lane == 0) ? 0.5f : 1.0f;
 
     // T = 2 fetches the samples of frame g+1 at the top of frame g (+32 VGPRs throughout).  T = 4 has no registers to
     // spare and loads at the top of the frame; fetching late, as the split pass frees registers, or whole frames ahead at
@@ -240,9 +244,9 @@ __global__ __launch_bounds__(64 * WavesFor<T>::value, T == 4 ? SG_RBIG4_OCC : 4)
                 const float2 D = make_float2(A.x - B.x, A.y + B.y);
                 const float2 Tt = make_float2(fmaf(cs.y, D.x, -cs.x * D.y), fmaf(cs.x, D.x, cs.y * D.y));
                 const float2 Xk = csub(S, Tt), Xm = cadd(S, Tt);
-                const float qq = c == 0 ? q0 : q_in;
-                float pk = fmaf(Xk.x, Xk.x, Xk.y * Xk.y) * qq;
-                float pm = fmaf(Xm.x, Xm.x, Xm.y * Xm.y) * qq;
+                float pk = fmaf(Xk.x, Xk.x, Xk.y * Xk.y);
+                float pm = fmaf(Xm.x, Xm.x, Xm.y * Xm.y);
+                if (MODE == 0 && c == 0) { pk *= r0; pm *= r0; }
                 if (MODE == 1) { pk = sqrtf(pk); pm = sqrtf(pm); }
                 const int k = lane + 64 * c;
                 orow[k] = pk;
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(64 * WavesFor<T>::value, T == 4 ? SG_RBIG4_OCC : 4)
         {   // k = M/2: lane 0, block c = R/2
             const float zx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, SG_Z(R / 2).x), 0));
             const float zy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, SG_Z(R / 2).y), 0));
-            float pq = fmaf(zx, zx, zy * zy) * (q_in * 4.0f);
+            float pq = fmaf(zx, zx, zy * zy) * 4.0f;
             if (MODE == 1) pq = sqrtf(pq);
             orow[M / 2] = pq;                                // wave-uniform store
         }

@@ -86,8 +86,14 @@ __global__ __launch_bounds__(64 * kWaves) void stft_rsmall_kernel(const SmallPar
     float2* const x3w = buf + g3 * RS + lu;                           // + L*t
     const float2* const x3b = buf + g3 * RS + (M - lu);               // - L*t
 
+    // sqrt of the PSD scale rides on the window registers (stft_r8x3.hip); per group only the 1/2 on bins 0 and M is left
     const float q_in = MODE == 0 ? p.scale * 0.5f : p.scale * 0.25f;
-    const float q0 = lu == 0 ? p.scale * 0.25f : q_in;
+    {
+        const float sq = sqrtf(q_in);
+#pragma unroll
+        for (int a = 0; a < R; ++a) { w[a].x *= sq; w[a].y *= sq; }
+    }
+    const float r0 = (MODE == 0 && lu == 0) ? 0.5f : 1.0f;
 
     // loads of group q+1 are issued before the FFT of group q (one group of register prefetch)
     auto load_group = [&](int clip, int gi, float2 (&dst)[8]) {
@@ -172,9 +178,9 @@ __global__ __launch_bounds__(64 * kWaves) void stft_rsmall_kernel(const SmallPar
             const float2 D = make_float2(A.x - B.x, A.y + B.y);
             const float2 T = make_float2(fmaf(cs.y, D.x, -cs.x * D.y), fmaf(cs.x, D.x, cs.y * D.y));
             const float2 Xk = csub(S, T), Xm = cadd(S, T);
-            const float qq = t == 0 ? q0 : q_in;
-            float pk = fmaf(Xk.x, Xk.x, Xk.y * Xk.y) * qq;
-            float pm = fmaf(Xm.x, Xm.x, Xm.y * Xm.y) * qq;
+            float pk = fmaf(Xk.x, Xk.x, Xk.y * Xk.y);
+            float pm = fmaf(Xm.x, Xm.x, Xm.y * Xm.y);
+            if (MODE == 0 && t == 0) { pk *= r0; pm *= r0; }
             if (MODE == 1) { pk = sqrtf(pk); pm = sqrtf(pm); }
             const int k = lu + L * t;
             if (live) {
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(64 * kWaves) void stft_rsmall_kernel(const SmallPar
             }
         }
         if (live && lu == 0) {                                         // k = M/2 pairs with itself: |Z[M/2]|^2
-            float pq = fmaf(a[4].x, a[4].x, a[4].y * a[4].y) * (q_in * 4.0f);
+            float pq = fmaf(a[4].x, a[4].x, a[4].y * a[4].y) * 4.0f;
             if (MODE == 1) pq = sqrtf(pq);
             orow[M / 2] = pq;
         }
