@@ -368,3 +368,33 @@ def test_mel_abi_shapes(nfft, n_mels, rows):
         d_out.download(got); _capi.stream_sync()
         assert np.allclose(got, ref, rtol=2e-5, atol=2e-6 * ref.max())
     d_in.free(); d_out.free(); bank.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_plotengine_fast_image_equals_pcolormesh_colours(dtype):
+    """settings['fast_image']: one imshow of the device-made RGBA image instead of a quad mesh -- same colours as
+    matplotlib's jet on the reference's normalised image, cell edges where pcolormesh(shading='auto') puts them."""
+    import time
+    from matplotlib import cm
+    from PlotEngine import PlotEngine
+    x = cfg1_signal().astype(dtype)
+    settings = {"nperseg": 256, "fmin": 0.0, "fmax": 4000.0, "log_scale": True, "mode_raw": "Spectrogram",
+                "mode_proc": "None", "draw_raw": False, "draw_proc": False}
+    slow, fast = PlotEngine(), PlotEngine()
+    t0 = time.perf_counter(); slow.plot_extra(x, None, 16000.0, settings); t_slow = time.perf_counter() - t0
+    t0 = time.perf_counter(); fast.plot_extra(x, None, 16000.0, dict(settings, fast_image=True)); t_fast = time.perf_counter() - t0
+    np.testing.assert_array_equal(fast.last_Sxx, slow.last_Sxx)
+    assert len(fast.ax_spec.images) == 1 and not fast.ax_spec.collections
+    im = fast.ax_spec.images[0]
+    rgba = np.asarray(im.get_array())
+    f64 = slow.last_Sxx.dtype == np.float64
+    _, _, _, ref_img = orc.plot_image(slow.last_f, slow.last_t, slow.last_Sxx.astype(np.float64), 0.0, 4000.0, True)
+    want = cm.jet(ref_img, bytes=True)
+    assert rgba.shape == want.shape
+    # an image value that sits on a colour-table boundary may fall either side in f32: allow a step of the 256-entry table
+    assert (np.abs(rgba.astype(int) - want.astype(int)).max(axis=-1) <= (0 if f64 else 6)).mean() > 0.999
+    t, f = slow.last_t, slow.last_f
+    ext = im.get_extent()
+    assert np.allclose(ext, (t[0] - (t[1] - t[0]) / 2, t[-1] + (t[1] - t[0]) / 2, f[0] - (f[1] - f[0]) / 2, f[-1] + (f[1] - f[0]) / 2))
+    assert fast.ax_spec.get_xlim() == slow.ax_spec.get_xlim() and fast.ax_spec.get_ylim() == slow.ax_spec.get_ylim()
+    print(f"plot_extra: pcolormesh {t_slow*1e3:.1f} ms, imshow {t_fast*1e3:.1f} ms")
