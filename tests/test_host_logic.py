@@ -277,7 +277,7 @@ GLOO_SCRIPT = textwrap.dedent('''
     else:
         assert res is None
     dist.barrier(); dist.destroy_process_group()
-    print("rank", rank, "ok")
+    os.write(1, ("rank %d ok" % rank + chr(10)).encode())   # one write per rank: print() pieces of two ranks can interleave
 ''')
 
 
