@@ -1,77 +1,191 @@
-// HBM practical peaks on this device: read-only, write-only, copy (float4 per lane, grid-stride).
+// HBM practical ceilings on this device, measured the way a streaming kernel can actually drive the memory system:
+// U independent accesses in flight per lane (loads issued together, then the stores), grid swept over 1..32
+// workgroups per CU, 16 B and 4 B per lane, and the read : write mixes that matter for the STFT path
+// (read-only, write-only, 1:1 copy, 1:2 = hop 256 in / 513 bins out).  Buffers are 2 GiB (read) and 4 GiB (written),
+// far past the 256 MiB Infinity Cache.  Prints the best grid per row and the whole sweep.
+//
+//   hipcc --offload-arch=gfx950 -O3 -o hbm_peaks.bin hbm_peaks.hip && ./hbm_peaks.bin
+//
+// MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy; the round-1 version of this file (one access in flight per
+// lane, grid fixed at 2048) under-drove the chip and read 4.7-4.9 TB/s for the same copy.
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+#include <cstdlib>
+#include <cstring>
+#include <chrono>
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-template <int MODE, int NT>   // 0 read, 1 write, 2 copy, 3 = read 1 : write 2 (like the STFT stream)
-__global__ __launch_bounds__(256) void k(const v4f* __restrict__ in, v4f* __restrict__ out, size_t n, float* sink) {
-    v4f acc = {0, 0, 0, 0};
-    const size_t stride = (size_t)gridDim.x * 256;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        if (MODE == 0) { acc += in[i]; }
-        else if (MODE == 1) { v4f v = {1.f, 2.f, 3.f, (float)i}; if (NT) __builtin_nontemporal_store(v, out + i); else out[i] = v; }
-        else if (MODE == 2) { v4f v = in[i]; if (NT) __builtin_nontemporal_store(v, out + i); else out[i] = v; }
-        else { v4f v = in[i]; if (NT) { __builtin_nontemporal_store(v, out + 2 * i); __builtin_nontemporal_store(v, out + 2 * i + 1); } else { out[2 * i] = v; out[2 * i + 1] = v; } }
+// MODE 0 read, 1 write, 2 copy, 3 read 1 : write 2.  T = v4f (16 B/lane) or float (4 B/lane).  U accesses in flight.
+// Block-cyclic: a workgroup takes tiles of 256*U elements, tile index strides by gridDim.x, so at any moment the whole
+// chip works on one compact window of the buffers.
+template <int MODE, typename T, int U>
+__global__ __launch_bounds__(256) void stream_k(const T* __restrict__ in, T* __restrict__ out, size_t n_tiles, float* sink) {
+    T acc = T{};
+    for (size_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const size_t base = t * (256 * U) + threadIdx.x;
+        T v[U];
+        if (MODE != 1) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = in[base + 256 * u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = acc + T{} + (float)(base + u);
+        }
+        if (MODE == 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc += v[u];
+        } else if (MODE == 1 || MODE == 2) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) out[base + 256 * u] = v[u];
+        } else {
+            const size_t ob = t * (512 * U) + threadIdx.x;
+#pragma unroll
+            for (int u = 0; u < U; ++u) { out[ob + 512 * u] = v[u]; out[ob + 512 * u + 256] = v[u]; }
+        }
     }
-    if (MODE == 0 && acc.x == 123.456f) *sink = acc.y;
+    if (MODE == 0) { const float* a = reinterpret_cast<const float*>(&acc); if (a[0] == 123.456f) *sink = a[0]; }
 }
 
-template <int MODE, int NT>
-int run(const char* name, v4f* a, v4f* b, size_t n, double bytes, float* sink) {
+// The STFT kernel's own stream shape: a persistent grid of waves, wave w owns a contiguous run of 2052-B rows, per
+// row it reads 1024 B (two 8-B loads per lane, prefetched one row ahead) and writes 513 floats with nine 4-B stores
+// (four ascending 256-B segments, four descending, one uniform) -- no arithmetic.  SHAPE 1 = the same rows written
+// as 16-B stores from a workgroup-wide contiguous span (what an LDS-staged epilogue would emit).
+template <int SHAPE>
+__global__ __launch_bounds__(256) void rows_k(const float* __restrict__ x, float* __restrict__ out, long n_rows, int n_waves, float* sink) {
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (SHAPE == 0) {
+        if (w >= n_waves) return;
+        const long g0 = n_rows * w / n_waves, g1 = n_rows * (w + 1) / n_waves;
+        float2 v = *reinterpret_cast<const float2*>(x + g0 * 256 + 2 * lane);
+        float2 u = *reinterpret_cast<const float2*>(x + g0 * 256 + 128 + 2 * lane);
+        for (long f = g0; f < g1; ++f) {
+            const float s = v.x + v.y + u.x + u.y;
+            if (f + 1 < g1) {
+                v = *reinterpret_cast<const float2*>(x + (f + 1) * 256 + 2 * lane);
+                u = *reinterpret_cast<const float2*>(x + (f + 1) * 256 + 128 + 2 * lane);
+            }
+            float* row = out + f * 513;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) { row[lane + 64 * m] = s; row[512 - lane - 64 * m] = s; }
+            row[256] = s;
+        }
+    } else {
+        // workgroup b owns rows [n_rows*b/nb, n_rows*(b+1)/nb): reads them 16 B per lane, writes the 513/256-times larger
+        // output span 16 B per lane, 4 accesses in flight
+        const int nb = gridDim.x;
+        const long r0 = n_rows * blockIdx.x / nb, r1 = n_rows * (blockIdx.x + 1) / nb;
+        const v4f* xi = reinterpret_cast<const v4f*>(x + r0 * 256);
+        const long n_in = (r1 - r0) * 64;                        // v4f elements
+        long ob = (r0 * 513) & ~3L;                              // aligned start inside the output
+        const long oe = (r1 * 513) & ~3L;
+        v4f* o = reinterpret_cast<v4f*>(out);
+        long oi = ob / 4 + threadIdx.x;
+        const long oend = oe / 4;
+        for (long i = threadIdx.x; i < n_in; i += 256 * 2) {
+            const v4f a = xi[i];
+            const v4f b = (i + 256 < n_in) ? xi[i + 256] : a;
+            // two loads feed four stores (1 : 2 bytes)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { if (oi < oend) o[oi] = (k & 1) ? b : a; oi += 256; }
+        }
+        if (sink && n_in < 0) *sink = 0;
+    }
+}
+
+static float* g_sink;
+static double g_best;
+
+template <int MODE, typename T, int U>
+void sweep(const char* name, const T* a, T* b, size_t bytes_in, double bytes_moved) {
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    const int grid = 256 * 8;
-    hipLaunchKernelGGL((k<MODE, NT>), dim3(grid), dim3(256), 0, 0, a, b, n, sink);
+    const size_t n_tiles = bytes_in / sizeof(T) / (256 * U);
+    double best = 0; int best_grid = 0;
+    printf("%-34s", name);
+    for (int per_cu = 1; per_cu <= 32; per_cu *= 2) {
+        const int grid = 256 * per_cu;
+        hipLaunchKernelGGL((stream_k<MODE, T, U>), dim3(grid), dim3(256), 0, 0, a, b, n_tiles, g_sink);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipEventRecord(e0));
+        const int reps = 4;
+        for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((stream_k<MODE, T, U>), dim3(grid), dim3(256), 0, 0, a, b, n_tiles, g_sink);
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        const double tbs = bytes_moved * reps / (ms * 1e-3) / 1e12;
+        printf(" %5.2f", tbs);
+        if (tbs > best) { best = tbs; best_grid = per_cu; }
+    }
+    printf("   best %.2f TB/s @ %d wg/CU\n", best, best_grid);
+    g_best = best;
+    fflush(stdout);
+}
+
+template <int SHAPE>
+void rows(const char* name, const float* x, float* out, int occ) {
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const long n_rows = 119808L * 8;                 // 8 cfg2 batches: 0.98 GB in, 1.97 GB out per launch
+    const int n_waves = 256 * 4 * occ, grid = n_waves / 4;
+    hipLaunchKernelGGL((rows_k<SHAPE>), dim3(grid), dim3(256), 0, 0, x, out, n_rows, n_waves, g_sink);
     CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(e0));
-    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((k<MODE, NT>), dim3(grid), dim3(256), 0, 0, a, b, n, sink);
+    const int reps = 4;
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((rows_k<SHAPE>), dim3(grid), dim3(256), 0, 0, x, out, n_rows, n_waves, g_sink);
     CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
-    printf("%-28s %.2f TB/s\n", name, bytes * 5 / (ms * 1e-3) / 1e12);
-    return 0;
+    const double bytes = (double)n_rows * 3076;
+    printf("%-34s occ %d waves/SIMD: %.2f TB/s  (%.1f us per 119808 rows)\n", name, occ, bytes * reps / (ms * 1e-3) / 1e12, ms * 1e3 / reps / 8);
+    fflush(stdout);
 }
 
-// 4-byte-per-lane streaming (what a row-per-wave epilogue emits) for comparison with the 16-byte forms above
-template <int MODE>
-__global__ __launch_bounds__(256) void k1(const float* __restrict__ in, float* __restrict__ out, size_t n, float* sink) {
-    float acc = 0.f;
-    const size_t stride = (size_t)gridDim.x * 256;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        if (MODE == 0) acc += in[i];
-        else if (MODE == 1) out[i] = (float)i;
-        else { const float v = in[i]; out[2 * i] = v; out[2 * i + 1] = v; }
-    }
-    if (MODE == 0 && acc == 123.456f) *sink = acc;
-}
-template <int MODE>
-int run1(const char* name, float* a, float* b, size_t n, double bytes, float* sink) {
-    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    const int grid = 256 * 8;
-    hipLaunchKernelGGL((k1<MODE>), dim3(grid), dim3(256), 0, 0, a, b, n, sink);
-    CHECK(hipDeviceSynchronize());
-    CHECK(hipEventRecord(e0));
-    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((k1<MODE>), dim3(grid), dim3(256), 0, 0, a, b, n, sink);
-    CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
-    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
-    printf("%-28s %.2f TB/s\n", name, bytes * 5 / (ms * 1e-3) / 1e12);
-    return 0;
-}
-
-int main() {
-    const size_t bytes = (size_t)2 << 30;      // 2 GiB per buffer
-    v4f *a, *b; float* sink;
-    CHECK(hipMalloc(&a, bytes)); CHECK(hipMalloc(&b, 2 * bytes)); CHECK(hipMalloc(&sink, 4));
+int main(int argc, char** argv) {
+    const size_t bytes = (size_t)2 << 30;      // 2 GiB read buffer, 4 GiB written buffer
+    void *a, *b;
+    CHECK(hipMalloc(&a, bytes)); CHECK(hipMalloc(&b, 2 * bytes)); CHECK(hipMalloc(&g_sink, 4));
     CHECK(hipMemset(a, 0, bytes)); CHECK(hipMemset(b, 0, 2 * bytes));
-    const size_t n = bytes / 16;
-    run<0, 0>("read", a, b, n, (double)bytes, sink);
-    run<1, 0>("write", a, b, n, (double)bytes, sink);
-    run<1, 1>("write nt", a, b, n, (double)bytes, sink);
-    run<2, 0>("copy (r+w bytes)", a, b, n, 2.0 * bytes, sink);
-    run<2, 1>("copy nt", a, b, n, 2.0 * bytes, sink);
-    run<3, 0>("read1:write2", a, b, n, 3.0 * bytes, sink);
-    run<3, 1>("read1:write2 nt", a, b, n, 3.0 * bytes, sink);
-    run1<0>("read dword", (float*)a, (float*)b, bytes / 4, (double)bytes, sink);
-    run1<1>("write dword", (float*)a, (float*)b, bytes / 4, (double)bytes, sink);
-    run1<2>("read1:write2 dword", (float*)a, (float*)b, bytes / 4, 3.0 * bytes, sink);
+    hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
+    printf("device %s, %d CUs; columns = 1 2 4 8 16 32 workgroups (256 threads) per CU; TB/s of bytes moved\n", prop.gcnArchName, prop.multiProcessorCount);
+    const v4f* a4 = (const v4f*)a; v4f* b4 = (v4f*)b; const float* a1 = (const float*)a; float* b1 = (float*)b;
+    const double B = (double)bytes;
+    if (argc > 2 && !strcmp(argv[1], "sustain")) {     // ./hbm_peaks.bin sustain <rows|read|write|mix> [secs]: a steady stream for tools/telemetry.py
+        const double secs = argc > 3 ? atof(argv[3]) : 4.0;
+        auto t0 = std::chrono::steady_clock::now();
+        long n = 0; double el = 0;
+        while (el < secs) {
+            for (int i = 0; i < 4; ++i) {
+                if (!strcmp(argv[2], "rows")) hipLaunchKernelGGL((rows_k<0>), dim3(2048), dim3(256), 0, 0, a1, b1, 119808L * 8, 8192, g_sink);
+                else if (!strcmp(argv[2], "read")) hipLaunchKernelGGL((stream_k<0, v4f, 4>), dim3(512), dim3(256), 0, 0, a4, b4, bytes / 16 / 1024, g_sink);
+                else if (!strcmp(argv[2], "write")) hipLaunchKernelGGL((stream_k<1, v4f, 4>), dim3(256), dim3(256), 0, 0, a4, b4, bytes / 16 / 1024, g_sink);
+                else hipLaunchKernelGGL((stream_k<3, float, 16>), dim3(256), dim3(256), 0, 0, a1, b1, bytes / 4 / 4096, g_sink);
+            }
+            CHECK(hipDeviceSynchronize());
+            n += 4;
+            el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        }
+        const double per = !strcmp(argv[2], "rows") ? 119808.0 * 8 * 3076 : !strcmp(argv[2], "mix") ? 3 * B : B;
+        printf("sustain %s: %.2f TB/s over %.1f s\n", argv[2], per * n / el / 1e12, el);
+        return 0;
+    }
+    sweep<0, v4f, 1>("read   16B x1", a4, b4, bytes, B);
+    sweep<0, v4f, 4>("read   16B x4", a4, b4, bytes, B);
+    sweep<0, v4f, 8>("read   16B x8", a4, b4, bytes, B);
+    sweep<1, v4f, 1>("write  16B x1", a4, b4, bytes, B);
+    sweep<1, v4f, 4>("write  16B x4", a4, b4, bytes, B);
+    sweep<1, v4f, 8>("write  16B x8", a4, b4, bytes, B);
+    sweep<2, v4f, 1>("copy   16B x1 (r+w)", a4, b4, bytes, 2 * B);
+    sweep<2, v4f, 4>("copy   16B x4 (r+w)", a4, b4, bytes, 2 * B);
+    sweep<2, v4f, 8>("copy   16B x8 (r+w)", a4, b4, bytes, 2 * B);
+    sweep<3, v4f, 1>("r1:w2  16B x1", a4, b4, bytes, 3 * B);
+    sweep<3, v4f, 4>("r1:w2  16B x4", a4, b4, bytes, 3 * B);
+    sweep<3, v4f, 8>("r1:w2  16B x8", a4, b4, bytes, 3 * B);
+    sweep<0, float, 4>("read    4B x4", a1, b1, bytes, B);
+    sweep<0, float, 16>("read    4B x16", a1, b1, bytes, B);
+    sweep<1, float, 4>("write   4B x4", a1, b1, bytes, B);
+    sweep<1, float, 16>("write   4B x16", a1, b1, bytes, B);
+    sweep<2, float, 16>("copy    4B x16 (r+w)", a1, b1, bytes, 2 * B);
+    sweep<3, float, 4>("r1:w2   4B x4", a1, b1, bytes, 3 * B);
+    sweep<3, float, 16>("r1:w2   4B x16", a1, b1, bytes, 3 * B);
+    for (int occ : {1, 2, 4, 8}) rows<0>("stft rows: 2x8B in, 9x4B out/row", a1, b1, occ);
+    for (int occ : {1, 2, 4, 8}) rows<1>("stft rows, 16B contiguous spans", a1, b1, occ);
     return 0;
 }
