@@ -142,6 +142,23 @@ int sg_stft_band_power(const sg_plan* plan, const void* x_dev, int64_t n_samples
                        int64_t clip_stride, int n_clips, int k_lo, int k_hi,
                        void* band_out_dev, int64_t out_clip_stride, void* stream);
 
+/*
+ * The log display of PlotEngine.py:126-131 fused into the STFT kernel for a caller-supplied global_max (the batch-global
+ * normalisation base of PlotEngine.py:110,126): for every frame only
+ *     db[frame][k - k_lo] = 10*log10(clip(Sxx[k]/(global_max + 1e-20), 0, 1) + 1e-12),   k_lo <= k <= k_hi,
+ * is written (db_dev: [n_clips][n_frames][k_hi-k_lo+1] f32, clip c at db_dev + c*out_clip_stride) and mm_dev[0..1]
+ * receives the minimum and maximum of the dB values over the whole call (per-wave partials folded by one small kernel on
+ * the same stream), so the min-max rescale of :130-131 costs no further pass over the spectrum: fold it into the consumer
+ * (sg_colormap_db) or apply it in place (sg_db_rescale).  Needs an f32 nperseg = nfft = 1024 PSD plan
+ * (sg_plan_kernel == "r8x3") and global_max > 0; SG_ERR_UNSUPPORTED / SG_ERR_ARG otherwise (other plans:
+ * sg_stft + sg_normalise_image).  Asynchronous.
+ */
+int sg_stft_db(const sg_plan* plan, const float* x_dev, int64_t n_samples, int64_t clip_stride, int n_clips,
+               int k_lo, int k_hi, double global_max, float* db_dev, int64_t out_clip_stride, float* mm_dev,
+               void* stream);
+/* db <- (db - mm[0]) / (mm[1] - mm[0]) in place, zeros when mm[1] - mm[0] <= 1e-6 (PlotEngine.py:130-131); n elements. */
+int sg_db_rescale(float* db_dev, int64_t n, const float* mm_dev, void* stream);
+
 /* ---- epilogues over a frame-major spectrum (A8..A13) ------------------ */
 /* `dtype` (sg_dtype) is the element type of every spectrum / image / band buffer below.
  * The reductions (sg_minmax, sg_normalise_image, sg_band_totals) run in two stages through a 256 KiB scratch that the
@@ -180,6 +197,11 @@ int sg_slice_bins(const void* spec_dev, int dtype, int64_t n_frames, int n_bins,
 int sg_jet_lut(uint8_t* rgba_host);
 /* rgba_dev[i] = lut_dev[clamp(int(img[i]*256), 0, 255)] (NaN -> transparent black), img f32 in [0,1]; n elements. */
 int sg_colormap(const float* img_dev, int64_t n, const uint8_t* lut_dev /* [256][4] */, uint8_t* rgba_dev, void* stream);
+
+/* sg_colormap of the min-max rescaled dB image without materialising it: v = (db - mm[0])/(mm[1] - mm[0]) (0 when the
+ * range is <= 1e-6), rgba = lut[clamp(int(v*256), 0, 255)]. */
+int sg_colormap_db(const float* db_dev, int64_t n, const float* mm_dev, const uint8_t* lut_dev, uint8_t* rgba_dev,
+                   void* stream);
 
 /* ---- mel filterbank (BASELINE cfg3; NOT in the reference: definition is this library's own) ---- */
 /*

@@ -318,6 +318,8 @@ inline int after_launch(const char* what) {
     return e == hipSuccess ? SG_OK : hip_fail(e, what);
 }
 
+}  // namespace
+
 // Scratch for the partials, one small buffer per (device, stream): launches on a stream are ordered, so successive
 // reductions on it may share the buffer.  Lives until the library is unloaded.
 void* reduction_scratch(hipStream_t s) {
@@ -330,6 +332,8 @@ void* reduction_scratch(hipStream_t s) {
     if (!p && hipMalloc(&p, sizeof(double) * 16 * kMaxParts) != hipSuccess) p = nullptr;
     return p;
 }
+
+namespace {
 
 // how to walk band [k_lo, k_hi] of an (n_frames x n_bins) spectrum; `flat` = the band is every bin, so the data
 // is contiguous and both it and a packed output can be read 16 B per lane
@@ -378,7 +382,50 @@ int normalise_t(const void* spec, int64_t n_frames, int n_bins, int k_lo, int k_
     return after_launch("normalise");
 }
 
+// img <- (img - lo) / (hi - lo), or 0 when hi - lo <= 1e-6 (PlotEngine.py:130-131), mm = (lo, hi) on the device
+__global__ __launch_bounds__(kThreads) void rescale_kernel(float* img, int64_t n, const float* mm) {
+    const float lo = mm[0], range = mm[1] - mm[0];
+    const bool degenerate = !(range > 1e-6f);
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
+    const int64_t i0 = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+    if ((reinterpret_cast<uintptr_t>(img) & 15) == 0) {
+        float4* const v4 = reinterpret_cast<float4*>(img);
+        for (int64_t i = i0; i < n / 4; i += stride) {
+            float4 v = v4[i];
+            v.x = degenerate ? 0.f : (v.x - lo) / range; v.y = degenerate ? 0.f : (v.y - lo) / range;
+            v.z = degenerate ? 0.f : (v.z - lo) / range; v.w = degenerate ? 0.f : (v.w - lo) / range;
+            v4[i] = v;
+        }
+        for (int64_t i = (n / 4) * 4 + i0; i < n; i += stride) img[i] = degenerate ? 0.f : (img[i] - lo) / range;
+    } else {
+        for (int64_t i = i0; i < n; i += stride) img[i] = degenerate ? 0.f : (img[i] - lo) / range;
+    }
+}
+
+// colour mapping with the min-max rescale folded in: rgba = lut[int(((img - lo) / (hi - lo)) * 256)]
+__global__ __launch_bounds__(kThreads) void colormap_affine_kernel(const float* img, int64_t n, const float* mm, const uchar4* lut, uchar4* rgba) {
+    const float lo = mm[0], range = mm[1] - mm[0];
+    const bool degenerate = !(range > 1e-6f);
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kThreads) {
+        const float d = img[i];
+        const float v = degenerate ? 0.f : (d - lo) / range;
+        uchar4 c = make_uchar4(0, 0, 0, 0);
+        if (v == v) {
+            int idx = static_cast<int>(v * 256.0f);
+            idx = idx < 0 ? 0 : (idx > 255 ? 255 : idx);
+            c = lut[idx];
+        }
+        rgba[i] = c;
+    }
+}
+
 }  // namespace
+
+int fold_minmax_f32(const float* parts, int n_parts, float* mm_dev, hipStream_t s) {
+    hipLaunchKernelGGL(minmax_fold_kernel<float>, dim3(1), dim3(kThreads), 0, s, parts, n_parts, mm_dev);
+    return after_launch("minmax fold");
+}
+
 }  // namespace sg
 
 using namespace sg;
@@ -428,6 +475,21 @@ int sg_colormap(const float* img_dev, int64_t n, const uint8_t* lut_dev, uint8_t
     hipLaunchKernelGGL(colormap_kernel, dim3(grid_for(n)), dim3(kThreads), 0, static_cast<hipStream_t>(stream), img_dev, n,
                        reinterpret_cast<const uchar4*>(lut_dev), reinterpret_cast<uchar4*>(rgba_dev));
     return after_launch("colormap");
+}
+
+int sg_db_rescale(float* db_dev, int64_t n, const float* mm_dev, void* stream) {
+    if (n < 0 || (n > 0 && (!db_dev || !mm_dev))) { set_error("sg_db_rescale: bad argument"); return SG_ERR_ARG; }
+    if (n == 0) return SG_OK;
+    hipLaunchKernelGGL(rescale_kernel, dim3(grid_for((n + 3) / 4)), dim3(kThreads), 0, static_cast<hipStream_t>(stream), db_dev, n, mm_dev);
+    return after_launch("db rescale");
+}
+
+int sg_colormap_db(const float* db_dev, int64_t n, const float* mm_dev, const uint8_t* lut_dev, uint8_t* rgba_dev, void* stream) {
+    if (n < 0 || (n > 0 && (!db_dev || !mm_dev || !lut_dev || !rgba_dev))) { set_error("sg_colormap_db: bad argument"); return SG_ERR_ARG; }
+    if (n == 0) return SG_OK;
+    hipLaunchKernelGGL(colormap_affine_kernel, dim3(grid_for(n)), dim3(kThreads), 0, static_cast<hipStream_t>(stream), db_dev, n, mm_dev,
+                       reinterpret_cast<const uchar4*>(lut_dev), reinterpret_cast<uchar4*>(rgba_dev));
+    return after_launch("colormap db");
 }
 
 int sg_minmax(const void* spec_dev, int dtype, int64_t n_frames, int n_bins, int k_lo, int k_hi, void* mm_dev, void* stream) {

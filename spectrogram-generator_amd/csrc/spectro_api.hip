@@ -391,6 +391,43 @@ int sg_stft_band_power(const sg_plan* plan, const void* x_dev, int64_t n_samples
     return run_stft(plan, a);
 }
 
+int sg_stft_db(const sg_plan* plan, const float* x_dev, int64_t n_samples, int64_t clip_stride, int n_clips, int k_lo, int k_hi,
+               double global_max, float* db_dev, int64_t out_clip_stride, float* mm_dev, void* stream) {
+    if (!plan) { set_error("null plan"); return SG_ERR_ARG; }
+    if (plan->kernel != Kernel::R8X3 || plan->mode != SG_MODE_PSD) {
+        set_error("sg_stft_db needs an f32 nperseg = nfft = 1024 psd plan (r8x3); use sg_stft + sg_normalise_image");
+        return SG_ERR_UNSUPPORTED;
+    }
+    if (!(global_max > 0.0) || !std::isfinite(global_max)) { set_error("sg_stft_db: global_max must be positive and finite (the batch-global base of PlotEngine.py:126)"); return SG_ERR_ARG; }
+    const int nbins = plan->nfft / 2 + 1;
+    if (k_lo < 0 || k_hi >= nbins || k_lo > k_hi) { set_error("bad band [%d,%d] of %d bins", k_lo, k_hi, nbins); return SG_ERR_ARG; }
+    if (!mm_dev) { set_error("null device pointer"); return SG_ERR_ARG; }
+    if (n_clips < 0 || n_samples < 0) { set_error("negative sizes"); return SG_ERR_ARG; }
+    auto s = static_cast<hipStream_t>(stream);
+    const int64_t n_frames = n_samples < plan->nperseg ? 0 : (n_samples - plan->nperseg) / plan->hop + 1;
+    if (n_frames == 0 || n_clips == 0) {       // empty image: (min, max) = (+inf, -inf), like an empty reduction
+        const float e[2] = {INFINITY, -INFINITY};
+        SG_HIP(hipMemcpyAsync(mm_dev, e, sizeof(e), hipMemcpyHostToDevice, s));
+        SG_HIP(hipStreamSynchronize(s));
+        return SG_OK;
+    }
+    if (!x_dev || !db_dev) { set_error("null device pointer"); return SG_ERR_ARG; }
+    if (n_clips > 1 && clip_stride < n_samples) { set_error("clip_stride < n_samples"); return SG_ERR_ARG; }
+    const int64_t need = n_frames * (k_hi - k_lo + 1);
+    if (n_clips > 1 && out_clip_stride < need) { set_error("out_clip_stride %lld < %lld", (long long)out_clip_stride, (long long)need); return SG_ERR_ARG; }
+    void* parts = reduction_scratch(s);
+    if (!parts) { set_error("sg_stft_db: no scratch memory"); return SG_ERR_HIP; }
+    StftArgs a{};
+    a.x = x_dev; a.in_i16 = 0; a.n_samples = n_samples; a.clip_stride = clip_stride; a.n_clips = n_clips;
+    a.out = db_dev; a.out_clip_stride = out_clip_stride; a.n_frames = n_frames; a.k_lo = k_lo; a.k_hi = k_hi;
+    a.db_mode = 1; a.inv_base = 1.0f / (static_cast<float>(global_max) + 1e-20f); a.mm_parts = parts; a.stream = s;
+    if (n_frames > INT32_MAX) { set_error("more than 2^31 frames per clip"); return SG_ERR_ARG; }
+    const int n_parts = r8x3_grid_waves(*plan, n_frames * n_clips);      // <= 4 waves x 4 SIMDs x CUs = 4096 pairs of 8 B
+    if (static_cast<size_t>(n_parts) * 8 > sizeof(double) * 16 * 2048) { set_error("sg_stft_db: partials exceed the scratch"); return SG_ERR_HIP; }
+    if (int rc = launch_r8x3(*plan, a)) return rc;
+    return fold_minmax_f32(static_cast<const float*>(parts), n_parts, mm_dev, s);
+}
+
 int sg_time_stft(const sg_plan* plan, const void* x_dev, int64_t n_samples, int64_t clip_stride, int n_clips,
                  void* out_dev, int64_t out_clip_stride, void* stream, int iters, float* ms_per_launch) {
     if (!ms_per_launch || iters < 1) { set_error("bad argument"); return SG_ERR_ARG; }

@@ -84,16 +84,34 @@ struct R8Params {
     int hop;
     int64_t total_frames;  // n_frames * n_clips, flattened index g = clip * n_frames + f
     int n_waves;           // waves in the grid; wave w owns g in [w*total/n_waves, (w+1)*total/n_waves)
-    int run_len;           // 0: one contiguous run per wave; R > 0: runs of R frames dealt round-robin (tuning aid)
-    float* out;            // [clip][frame][513]   (MODE psd / magnitude) or [clip][frame] (BAND)
+    float* out;            // [clip][frame][513] (OUT_PSD / OUT_MAG), [clip][frame] (OUT_BAND), [clip][frame][k_hi-k_lo+1] (OUT_DB*)
     int64_t out_clip_stride;
     const float2* win2;    // [512]  (w[2n], w[2n+1])
     const float2* tw;      // [18][64]
     float scale;
-    int k_lo, k_hi;        // BAND only
+    int k_lo, k_hi;        // OUT_BAND, OUT_DB_BAND
+    float inv_base;        // OUT_DB*: 1 / (global_max + 1e-20)
+    float2* mm_parts;      // OUT_DB*: [n_waves] (min, max) of the dB values a wave wrote
 };
 
-// MODE: 0 = psd, 1 = magnitude.  BAND: write only sum_{k_lo..k_hi} per frame.
+// What a frame leaves in HBM.
+//   OUT_PSD / OUT_MAG  the 513-bin row (scipy mode 'psd' / 'magnitude')
+//   OUT_BAND           sum_{k_lo..k_hi} of the PSD row (A11, PlotEngine.py:238-239): 4 B per frame
+//   OUT_DB_FULL/_BAND  10*log10(clip(S/(gmax+1e-20), 0, 1) + 1e-12) of bins [k_lo, k_hi] (PlotEngine.py:126-129 with a
+//                      caller-supplied global_max, :110) plus the wave's min / max of what it wrote, so that the min-max
+//                      rescale of :130-131 needs no further pass over the spectrum
+enum { OUT_PSD = 0, OUT_MAG = 1, OUT_BAND = 2, OUT_DB_FULL = 3, OUT_DB_BAND = 4 };
+
+__device__ __forceinline__ float wave_min_f(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// OUT: see the enum above.
 // H: hop / 128 when the hop is a multiple of 128 samples (1..8), else 0.  With H > 0 consecutive frames of a
 // wave share registers: lane l keeps samples 2l + 128k (k = 0..7), the next frame needs k + H, so only H new
 // float2 per lane are fetched per frame and every sample is loaded once per wave.  In both cases the loads of
@@ -103,8 +121,11 @@ struct R8Params {
 // (clip, frame) index space, runs differ by at most one frame, so there is no tail of half-empty rounds.
 // Window and twiddles stay in VGPRs (SG_TW_LDS=0, ~118 VGPRs = 4 waves/SIMD); SG_TW_LDS=1 moves the twiddles to a
 // 9 KiB workgroup-shared LDS table (83 VGPRs = 5 waves/SIMD).
-template <typename TIn, bool ALIGNED, bool DETREND, int MODE, bool BAND, int H>
+template <typename TIn, bool ALIGNED, bool DETREND, int OUT, int H>
 __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_kernel(const R8Params p) {
+    constexpr bool BAND = OUT == OUT_BAND;
+    constexpr bool DB = OUT == OUT_DB_FULL || OUT == OUT_DB_BAND;
+    constexpr int MODE = OUT == OUT_MAG ? 1 : 0;
     __shared__ __attribute__((aligned(16))) float2 lds[kWavesPerWg * kSlab + (SG_TW_LDS ? 18 * 64 : 0)];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -120,8 +141,6 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
 
     const int lw = xcd_remap(blockIdx.x, gridDim.x) * kWavesPerWg + wave;     // logical wave index
     if (lw >= p.n_waves) return;
-    int64_t chunk = lw;
-    const int64_t n_chunks = p.run_len > 0 ? (p.total_frames + p.run_len - 1) / p.run_len : p.n_waves;
 
     float2 w[8];
 #pragma unroll
@@ -158,10 +177,11 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
         for (int a = 0; a < 8; ++a) { w[a].x *= sq; w[a].y *= sq; }
     }
     const float r0 = (MODE == 0 && lane == 0) ? 0.5f : 1.0f;
+    float vmin = INFINITY, vmax = -INFINITY;         // OUT_DB*: this lane's extrema of the dB values written
+    const int row_len = DB ? p.k_hi - p.k_lo + 1 : kBins;
 
-    for (; chunk < n_chunks; chunk += p.n_waves) {
-    int64_t g = p.run_len > 0 ? chunk * p.run_len : p.total_frames * lw / p.n_waves;
-    const int64_t g_end = p.run_len > 0 ? min(g + p.run_len, p.total_frames) : p.total_frames * (lw + 1) / p.n_waves;
+    int64_t g = p.total_frames * lw / p.n_waves;
+    const int64_t g_end = p.total_frames * (lw + 1) / p.n_waves;
     while (g < g_end) {                              // one iteration per clip touched by this run (1 or 2)
         const int clip = static_cast<int>(g / p.n_frames);
         const int f0 = static_cast<int>(g - static_cast<int64_t>(clip) * p.n_frames);
@@ -169,8 +189,10 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
         g += f1 - f0;
 
         const TIn* const xclip = static_cast<const TIn*>(p.x) + static_cast<int64_t>(clip) * p.clip_stride + 2 * lane;
+        // (OUT_DB_BAND: orow[k] is bin k's slot, i.e. the row start minus k_lo)
         float* orow = BAND ? p.out + static_cast<int64_t>(clip) * p.out_clip_stride + f0
-                           : p.out + static_cast<int64_t>(clip) * p.out_clip_stride + static_cast<int64_t>(f0) * kBins;
+                           : p.out + static_cast<int64_t>(clip) * p.out_clip_stride + static_cast<int64_t>(f0) * row_len -
+                                 (OUT == OUT_DB_BAND ? p.k_lo : 0);
         const TIn* src = xclip + static_cast<int64_t>(f0) * p.hop;
 
         float2 raw[8];
@@ -230,6 +252,22 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
             // ---- split pass + |X|^2 epilogue (A5 tail + A6) ----------------------
             if (SG_R8_PRIO) __builtin_amdgcn_s_setprio(3);
             float band = 0.f;
+            auto emit = [&](int k, float v) {          // bin k of this frame
+                if (BAND) {
+                    band += (k >= p.k_lo && k <= p.k_hi) ? v : 0.f;
+                } else if (DB) {
+                    // PlotEngine.py:126-129; S >= 0, so only the upper clip acts; fminf also maps a NaN bin to 1 -> ~0 dB,
+                    // which is what np.nan_to_num leaves of it
+                    const float d = 3.01029995663981195f * __log2f(fminf(v * p.inv_base, 1.0f) + 1e-12f);
+                    if (OUT == OUT_DB_FULL || (k >= p.k_lo && k <= p.k_hi)) {
+                        orow[k] = d;
+                        vmin = fminf(vmin, d);
+                        vmax = fmaxf(vmax, d);
+                    }
+                } else {
+                    orow[k] = v;
+                }
+            };
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const float2 A = a[m];
@@ -245,13 +283,8 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
                 if (MODE == 0 && m == 0) { pk *= r0; pm *= r0; }
                 if (MODE == 1) { pk = sqrtf(pk); pm = sqrtf(pm); }
                 const int k = lane + 64 * m;
-                if (BAND) {
-                    band += (k >= p.k_lo && k <= p.k_hi) ? pk : 0.f;
-                    band += (kM - k >= p.k_lo && kM - k <= p.k_hi) ? pm : 0.f;
-                } else {
-                    orow[k] = pk;
-                    orow[kM - k] = pm;
-                }
+                emit(k, pk);
+                emit(kM - k, pm);
             }
             {   // k = 256 pairs with itself: X[256] = conj(Z[256]); Z[256] is lane 0's a[4]
                 const float zx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a[4].x), 0));
@@ -263,7 +296,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
                 } else {
                     // every lane holds the same pq: a wave-uniform store keeps the loop branch-free, so the
                     // compiler's s_waitcnt for the prefetched loads stays exact (vmcnt = stores issued since)
-                    orow[256] = pq;
+                    emit(256, pq);
                 }
             }
             if (BAND) {
@@ -271,15 +304,17 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
                 if (lane == 0) *orow = tot;
                 orow += 1;
             } else {
-                orow += kBins;
+                orow += row_len;
             }
             wave_lds_fence();    // next frame's exchange-1 writes stay behind these reads
         };
 
         // (fetching two frames ahead, so that two frames of stores may be in flight behind a request, measured slower:
         //  94.3 vs 90.0 us)
-        // (rotating the sample window through its registers -- hop = 2 registers: unrolled by four, no moves -- saves the
-        //  six 64-bit moves per frame but needs 142 VGPRs: 83.6-84.7 us at 3 waves/SIMD against 84.3-85.1, not worth 4x the code)
+        // (rotating the sample window through its registers instead of shifting it -- the frame loop unrolled over the
+        //  8 / gcd(8, H) rotations, no v_mov -- measured twice: round 1 83.6-84.7 vs 84.3-85.1 us at 142 VGPRs, round 2
+        //  97.8 us at 144 VGPRs / 3 waves per SIMD and 119.7 us with the spills of 128 VGPRs against 89.2 us rolled;
+        //  profiles/r02_ab_rotation.txt)
         for (int f = f0; f < f1; ++f) {
             float2 a[8];
 #pragma unroll
@@ -300,52 +335,73 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
             process(a);
         }
     }
+    if (DB) {
+        vmin = wave_min_f(vmin);
+        vmax = wave_max_f(vmax);
+        if (lane == 0) p.mm_parts[lw] = make_float2(vmin, vmax);
     }
 }
 
-template <typename TIn, bool ALIGNED, bool DETREND, int MODE, bool BAND, int H>
+template <typename TIn, bool ALIGNED, bool DETREND, int OUT, int H>
 int launch_h(const R8Params& prm, int n_wg, hipStream_t stream) {
-    hipLaunchKernelGGL((stft1024_r8x3_kernel<TIn, ALIGNED, DETREND, MODE, BAND, H>), dim3(n_wg), dim3(64 * kWavesPerWg), 0,
+    hipLaunchKernelGGL((stft1024_r8x3_kernel<TIn, ALIGNED, DETREND, OUT, H>), dim3(n_wg), dim3(64 * kWavesPerWg), 0,
                        stream, prm);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "stft1024_r8x3 launch");
     return SG_OK;
 }
 
-// register-sliding variants exist for aligned f32 input at the hops that matter (128, 256, 512, 896 = the
+// register-rotating variants exist for aligned f32 input at the hops that matter (128, 256, 512, 896 = the
 // reference default n - n/8); everything else takes the H = 0 prefetch path.
-template <typename TIn, bool ALIGNED, bool DETREND, int MODE, bool BAND>
+template <typename TIn, bool ALIGNED, bool DETREND, int OUT>
 int launch_one(const R8Params& prm, int n_wg, hipStream_t stream) {
     if constexpr (std::is_same<TIn, float>::value && ALIGNED) {
         switch (prm.hop) {
-            case 128: return launch_h<TIn, ALIGNED, DETREND, MODE, BAND, 1>(prm, n_wg, stream);
-            case 256: return launch_h<TIn, ALIGNED, DETREND, MODE, BAND, 2>(prm, n_wg, stream);
-            case 512: return launch_h<TIn, ALIGNED, DETREND, MODE, BAND, 4>(prm, n_wg, stream);
-            case 896: return launch_h<TIn, ALIGNED, DETREND, MODE, BAND, 7>(prm, n_wg, stream);
+            case 128: return launch_h<TIn, ALIGNED, DETREND, OUT, 1>(prm, n_wg, stream);
+            case 256: return launch_h<TIn, ALIGNED, DETREND, OUT, 2>(prm, n_wg, stream);
+            case 512: return launch_h<TIn, ALIGNED, DETREND, OUT, 4>(prm, n_wg, stream);
+            case 896: return launch_h<TIn, ALIGNED, DETREND, OUT, 7>(prm, n_wg, stream);
             default: break;
         }
     }
-    return launch_h<TIn, ALIGNED, DETREND, MODE, BAND, 0>(prm, n_wg, stream);
+    return launch_h<TIn, ALIGNED, DETREND, OUT, 0>(prm, n_wg, stream);
 }
 
 template <typename TIn, bool ALIGNED, bool DETREND>
-int launch_mode(const R8Params& prm, int n_wg, hipStream_t s, int mode, bool band) {
-    if (band) return launch_one<TIn, ALIGNED, DETREND, 0, true>(prm, n_wg, s);
-    if (mode == SG_MODE_PSD) return launch_one<TIn, ALIGNED, DETREND, 0, false>(prm, n_wg, s);
-    return launch_one<TIn, ALIGNED, DETREND, 1, false>(prm, n_wg, s);
+int launch_out(const R8Params& prm, int n_wg, hipStream_t s, int out) {
+    switch (out) {
+        case OUT_PSD: return launch_one<TIn, ALIGNED, DETREND, OUT_PSD>(prm, n_wg, s);
+        case OUT_MAG: return launch_one<TIn, ALIGNED, DETREND, OUT_MAG>(prm, n_wg, s);
+        case OUT_BAND: return launch_one<TIn, ALIGNED, DETREND, OUT_BAND>(prm, n_wg, s);
+        default: break;
+    }
+    if constexpr (std::is_same<TIn, float>::value) {      // the dB image is wired for float input
+        if (out == OUT_DB_FULL) return launch_one<TIn, ALIGNED, DETREND, OUT_DB_FULL>(prm, n_wg, s);
+        if (out == OUT_DB_BAND) return launch_one<TIn, ALIGNED, DETREND, OUT_DB_BAND>(prm, n_wg, s);
+    }
+    set_error("r8x3: output form %d is not built for this input type", out);
+    return SG_ERR_UNSUPPORTED;
 }
 
 template <typename TIn>
-int launch_in(const R8Params& prm, int n_wg, hipStream_t s, bool aligned, bool detrend, int mode, bool band) {
+int launch_in(const R8Params& prm, int n_wg, hipStream_t s, bool aligned, bool detrend, int out) {
     if (aligned) {
-        return detrend ? launch_mode<TIn, true, true>(prm, n_wg, s, mode, band)
-                       : launch_mode<TIn, true, false>(prm, n_wg, s, mode, band);
+        return detrend ? launch_out<TIn, true, true>(prm, n_wg, s, out) : launch_out<TIn, true, false>(prm, n_wg, s, out);
     }
-    return detrend ? launch_mode<TIn, false, true>(prm, n_wg, s, mode, band)
-                   : launch_mode<TIn, false, false>(prm, n_wg, s, mode, band);
+    return detrend ? launch_out<TIn, false, true>(prm, n_wg, s, out) : launch_out<TIn, false, false>(prm, n_wg, s, out);
 }
 
 }  // namespace
+
+// persistent grid: kOccupancy waves per SIMD on every CU, but never runs shorter than kMinRun frames
+int r8x3_grid_waves(const sg_plan& p, int64_t total_frames) {
+    int occ = kOccupancy;
+    if (const char* e = getenv("SPECTRO_R8_OCC")) { const int v = atoi(e); if (v >= 1 && v <= kOccupancy) occ = v; }   // tuning aid
+    int64_t n_waves = static_cast<int64_t>(p.n_cu) * 4 * occ;
+    const int64_t by_work = (total_frames + kMinRun - 1) / kMinRun;
+    if (n_waves > by_work) n_waves = by_work;
+    return static_cast<int>(n_waves);
+}
 
 int launch_r8x3(const sg_plan& p, const StftArgs& a) {
     if (a.n_frames <= 0 || a.n_clips <= 0) return SG_OK;
@@ -356,16 +412,8 @@ int launch_r8x3(const sg_plan& p, const StftArgs& a) {
     prm.n_frames = static_cast<int>(a.n_frames);
     prm.hop = p.hop;
     prm.total_frames = a.n_frames * a.n_clips;
-    // persistent grid: kOccupancy waves per SIMD on every CU, but never runs shorter than kMinRun frames
-    int occ = kOccupancy;
-    if (const char* e = getenv("SPECTRO_R8_OCC")) { const int v = atoi(e); if (v >= 1 && v <= kOccupancy) occ = v; }   // tuning aid
-    int64_t n_waves = static_cast<int64_t>(p.n_cu) * 4 * occ;
-    const int64_t by_work = (prm.total_frames + kMinRun - 1) / kMinRun;
-    if (n_waves > by_work) n_waves = by_work;
-    int64_t n_wg = (n_waves + kWavesPerWg - 1) / kWavesPerWg;
-    prm.n_waves = static_cast<int>(n_waves);
-    prm.run_len = 0;
-    if (const char* e = getenv("SPECTRO_R8_RUN")) prm.run_len = atoi(e) > 0 ? atoi(e) : 0;   // tuning aid
+    prm.n_waves = r8x3_grid_waves(p, prm.total_frames);
+    const int n_wg = (prm.n_waves + kWavesPerWg - 1) / kWavesPerWg;
     prm.out = static_cast<float*>(a.out);
     prm.out_clip_stride = a.out_clip_stride;
     prm.win2 = static_cast<const float2*>(p.win_dev);
@@ -373,13 +421,20 @@ int launch_r8x3(const sg_plan& p, const StftArgs& a) {
     prm.scale = static_cast<float>(p.scale);
     prm.k_lo = a.k_lo;
     prm.k_hi = a.k_hi;
+    int out = a.band_mode ? OUT_BAND : (p.mode == SG_MODE_PSD ? OUT_PSD : OUT_MAG);
+    if (a.db_mode) {
+        if (p.mode != SG_MODE_PSD || !a.mm_parts) { set_error("r8x3: dB image needs a psd plan and a partials buffer"); return SG_ERR_ARG; }
+        out = (a.k_lo == 0 && a.k_hi == kBins - 1) ? OUT_DB_FULL : OUT_DB_BAND;
+        prm.inv_base = a.inv_base;
+        prm.mm_parts = static_cast<float2*>(a.mm_parts);
+    }
     const bool detrend = p.detrend == SG_DETREND_CONSTANT;
     if (a.in_i16) {
         const bool aligned = (p.hop % 2 == 0) && (a.clip_stride % 2 == 0) && (reinterpret_cast<uintptr_t>(a.x) % 4 == 0);
-        return launch_in<int16_t>(prm, static_cast<int>(n_wg), a.stream, aligned, detrend, p.mode, a.band_mode != 0);
+        return launch_in<int16_t>(prm, n_wg, a.stream, aligned, detrend, out);
     }
     const bool aligned = (p.hop % 2 == 0) && (a.clip_stride % 2 == 0) && (reinterpret_cast<uintptr_t>(a.x) % 8 == 0);
-    return launch_in<float>(prm, static_cast<int>(n_wg), a.stream, aligned, detrend, p.mode, a.band_mode != 0);
+    return launch_in<float>(prm, n_wg, a.stream, aligned, detrend, out);
 }
 
 // Per-lane twiddle table [18][64] (float2), computed in double:

@@ -56,6 +56,9 @@ SIGNATURES = {
     "sg_stft": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _i64, _vp]),
     "sg_stft_i16": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _i64, _vp]),
     "sg_stft_band_power": (_i, [_vp, _vp, _i64, _i64, _i, _i, _i, _vp, _i64, _vp]),
+    "sg_stft_db": (_i, [_vp, _vp, _i64, _i64, _i, _i, _i, _d, _vp, _i64, _vp, _vp]),
+    "sg_db_rescale": (_i, [_vp, _i64, _vp, _vp]),
+    "sg_colormap_db": (_i, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "sg_minmax": (_i, [_vp, _i, _i64, _i, _i, _i, _vp, _vp]),
     "sg_normalise_image": (_i, [_vp, _i, _i64, _i, _i, _i, _i, _d, _vp, _vp, _vp]),
     "sg_band_features": (_i, [_vp, _i, _i64, _vp, _vp]),
@@ -220,6 +223,10 @@ class Plan:
         check(lib().sg_stft_band_power(self.handle, C.c_void_p(x_ptr), int(n_samples), int(clip_stride), int(n_clips),
                                        int(k_lo), int(k_hi), C.c_void_p(out_ptr), int(out_clip_stride),
                                        C.c_void_p(stream)))
+
+    def stft_db(self, x_ptr, n_samples, clip_stride, n_clips, k_lo, k_hi, global_max, db_ptr, out_clip_stride, mm_ptr, stream=None):
+        check(lib().sg_stft_db(self.handle, C.c_void_p(x_ptr), int(n_samples), int(clip_stride), int(n_clips), int(k_lo), int(k_hi),
+                               float(global_max), C.c_void_p(db_ptr), int(out_clip_stride), C.c_void_p(mm_ptr), C.c_void_p(stream)))
 
     def time_stft(self, x_ptr, n_samples, clip_stride, n_clips, out_ptr, out_clip_stride, iters, stream=None):
         ms = C.c_float(0)
