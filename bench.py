@@ -7,8 +7,17 @@ One "step" = one pass of the hot path (framing -> detrend -> Hann window -> real
 density PSD) over one batch of synthetic clips already resident in HBM: BASELINE configs[1],
 64 clips x 10 s x 48 kHz f32 per GPU (119 808 frames, 368.7 MB of algorithmic traffic per step).
 For N > 1 the driver launches one rank per GPU with torch.distributed.run; clips shard across
-ranks with no data-path collective (weak scaling: every rank owns its own 64-clip batch); RCCL
-is used only for the barrier and the max-over-ranks time.  Rank 0 prints ONE JSON line.
+ranks with no data-path collective (weak scaling: every rank owns its own 64-clip batch;
+``--scaling strong`` shards ONE 64-clip batch instead); RCCL is used only for the barrier, the
+max-over-ranks time and -- after the timed region, reported separately as ``gather`` -- the
+gather of a reduced product (per-frame band power) to rank 0, which is the one exchange the path
+has (``--gather-full`` also times the full spectra).  Rank 0 prints ONE JSON line.
+
+What bounds the kernel is part of the line: ``roofline`` is the HBM roof (the graded fraction),
+``roofline.valu`` the VALU-issue roof, ``fp32_flops`` the arithmetic rate, and ``power`` the board power,
+power cap and shader clock read from the card's hwmon sensors during an untimed leg of back-to-back
+launches after the timed region -- the kernel runs AT the 1400 W cap (sclk ~1.9 of 2.4 GHz), so its time
+is energy / power rather than bytes / bandwidth or slots / issue rate.
 
 Defaults (500 timed steps after 100 warm-up steps, ~60 ms of GPU time) are long enough to get past the chip's
 power-management transient: the first ~12 launches run at 92 us, the next ~100 at up to 138 us, then the
@@ -21,9 +30,12 @@ sg_stft from libspectro.so, called through the C ABI on torch's current stream.
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
+import statistics
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -35,6 +47,16 @@ N_BINS = NPERSEG // 2 + 1
 BYTES_PER_FRAME = HOP * 4 + N_BINS * 4          # each sample read once, each bin written once
 HBM_PEAK_GBS = 8000.0                           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 N_BUFFER_SETS = 4                               # rotate so the 256 MiB Infinity Cache cannot hold a step's data
+# Arithmetic of one frame.  ALGORITHMIC: real FFT 2.5 n log2 n = 25 600 + detrend/window 3 n + epilogue
+# 4 (n/2 + 1) = 30 724 flop.  EXECUTED by stft1024_r8x3_kernel per wave = per frame (instruction mix of the frame loop,
+# profiles/r02_isa_mix_r8x3.txt, from `hipcc -S`): 321 VALU instructions = 367 issue slots (v_pk_add_f32 and v_mov_b64
+# hold the SIMD for two), 101 of them FMAs -> 423 flop per lane x 64 lanes.
+FLOP_PER_FRAME_ALGORITHMIC = 30724
+FLOP_PER_FRAME_EXECUTED = 423 * 64
+VALU_ISSUE_SLOTS_PER_FRAME = 367
+CYCLES_PER_SLOT = 2                              # a wave64 VALU instruction occupies its SIMD-32 for 2 cycles (MI355X_MICROARCH.md)
+SCLK_MAX_MHZ = 2400.0
+FP32_PEAK_TFLOPS = 157.3
 
 
 def parse():
@@ -43,12 +65,19 @@ def parse():
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--clips", type=int, default=CLIPS_PER_GPU, help="clips per GPU (default: BASELINE cfg2 = 64)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: every rank owns a --clips batch; strong: ONE --clips batch is sharded over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline work")
     ap.add_argument("--kernel", default=None, help="force a kernel family (debug): r8x3 | stockham")
     ap.add_argument("--settle-ms", type=float, default=60.0,
                     help="untimed back-to-back launches before the warm-up steps, so that the power-management transient "
                          "(first ~200 launches) is over whatever --warmup/--steps are (0 disables)")
+    ap.add_argument("--telemetry-s", type=float, default=1.5,
+                    help="seconds of untimed back-to-back launches AFTER the timed region during which rank 0 reads board "
+                         "power and shader clock from the card's hwmon nodes (0 disables)")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the (untimed-region) gather measurement")
+    ap.add_argument("--gather-full", action="store_true", help="N > 1: also time the gather of the full spectra to rank 0")
     return ap.parse_args()
 
 
@@ -63,6 +92,60 @@ def load_traffic():
     except (OSError, ValueError):
         pass
     return None
+
+
+class Telemetry:
+    """Board power / shader clock of ONE card (by PCI address) from its amdgpu hwmon nodes, polled from a thread."""
+
+    KEYS = ("freq1_input", "power1_average", "power1_input", "power1_cap")
+
+    def __init__(self, pci_bus_id: str, period: float = 0.02):
+        self.period, self.samples, self._stop, self._th = period, [], threading.Event(), None
+        self.paths = {}
+        for hw in glob.glob(f"/sys/bus/pci/devices/{pci_bus_id}/hwmon/hwmon*"):
+            for k in self.KEYS:
+                try:
+                    with open(f"{hw}/{k}") as fh:
+                        fh.read()
+                    self.paths[k] = f"{hw}/{k}"
+                except OSError:
+                    pass
+
+    @staticmethod
+    def _read(p):
+        try:
+            with open(p) as fh:
+                return float(fh.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def start(self):
+        def poll():
+            while not self._stop.is_set():
+                self.samples.append((time.perf_counter(), {k: self._read(p) for k, p in self.paths.items()}))
+                time.sleep(self.period)
+        if self.paths:
+            self._th = threading.Thread(target=poll, daemon=True)
+            self._th.start()
+        return self
+
+    def stop(self, skip_s: float):
+        """-> dict of medians over the samples taken after the first ``skip_s`` seconds (sensor averaging window), or None"""
+        if self._th is None:
+            return None
+        self._stop.set()
+        self._th.join()
+        if not self.samples:
+            return None
+        t0 = self.samples[0][0] + skip_s
+        rows = [s for t, s in self.samples if t >= t0] or [s for _, s in self.samples]
+        pkey = "power1_average" if rows[0].get("power1_average") is not None else "power1_input"
+
+        def med(key, div):
+            v = [r[key] / div for r in rows if r.get(key) is not None]
+            return statistics.median(v) if v else None
+        return {"board_W": med(pkey, 1e6), "cap_W": med("power1_cap", 1e6), "sclk_MHz": med("freq1_input", 1e6),
+                "n_samples": len(rows)}
 
 
 def main():
@@ -93,23 +176,29 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     from spectro import _capi
+    from spectro import dist as sdist
     from spectro.windows import get_window
     _capi.ensure_device(local_rank)
 
-    n_clips = args.clips
+    if args.scaling == "strong":
+        c0, c1 = sdist.shard_range(args.clips, world, rank)
+        n_clips = c1 - c0
+    else:
+        n_clips = args.clips
     plan = _capi.Plan(NPERSEG, NPERSEG, HOP, get_window("hann", NPERSEG), _capi.DETREND["constant"], FS,
                       _capi.SCALING["density"], _capi.MODE["psd"], _capi.F32)
     if args.kernel:
         plan.force_kernel(args.kernel)
     n_frames = plan.n_frames(N_SAMPLES)
-    frames_per_step = n_clips * n_frames
+    frames_per_step = n_clips * n_frames                       # this rank
+    total_frames_per_step = (args.clips if args.scaling == "strong" else args.clips * world) * n_frames
 
     # synthetic input: default_rng(1234 + rank) white noise * 0.1, f32, resident in HBM
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
-    xs = [torch.randn((n_clips, N_SAMPLES), device=dev, dtype=torch.float32, generator=gen) * 0.1
+    xs = [torch.randn((max(n_clips, 1), N_SAMPLES), device=dev, dtype=torch.float32, generator=gen) * 0.1
           for _ in range(N_BUFFER_SETS)]
-    outs = [torch.empty((n_clips, n_frames, N_BINS), device=dev, dtype=torch.float32) for _ in range(N_BUFFER_SETS)]
+    outs = [torch.empty((max(n_clips, 1), n_frames, N_BINS), device=dev, dtype=torch.float32) for _ in range(N_BUFFER_SETS)]
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     def step(i):
@@ -150,31 +239,89 @@ def main():
 
     # cheap sanity on the last output: finite and positive energy (full parity lives in tests/)
     last = outs[(args.steps - 1) % N_BUFFER_SETS]
-    ok = bool(torch.isfinite(last).all()) and float(last.sum()) > 0
+    ok = n_clips == 0 or (bool(torch.isfinite(last).all()) and float(last.sum()) > 0)
     if not ok:
         raise SystemExit("bench output is not finite/positive")
 
+    # ---- untimed legs -------------------------------------------------------------------------------------------
+    power = None
+    if rank == 0 and args.telemetry_s > 0 and n_clips > 0:
+        try:
+            tel = Telemetry(_capi.device_pci_bus_id()).start()
+            t_tel, i = time.perf_counter(), 0
+            while time.perf_counter() - t_tel < args.telemetry_s:
+                for _ in range(64):
+                    step(i)
+                    i += 1
+                torch.cuda.synchronize(dev)
+            power = tel.stop(skip_s=min(0.6, args.telemetry_s / 2))
+            if power:
+                power["us_per_launch_during_sample"] = (time.perf_counter() - t_tel) * 1e6 / i
+                power["sample"] = (f"{args.telemetry_s:g} s of back-to-back launches after the timed region; hwmon of "
+                                   f"{_capi.device_pci_bus_id()}, medians after the sensor's first 0.6 s")
+        except Exception as e:                                    # sensors are a report, never a failure
+            print(f"[bench] telemetry unavailable: {e}", file=sys.stderr)
+
+    gather = None
+    if world > 1 and not args.no_gather:
+        gather = time_gather(args, plan, xs[0], outs[0], n_clips, n_frames, dev, same_gpu, world, rank, stream)
+
     if rank == 0:
-        value = world * frames_per_step * args.steps / elapsed_max
+        value = total_frames_per_step * args.steps / elapsed_max
         launch_s = dev_ms_max / 1e3 / args.steps
-        achieved = frames_per_step * BYTES_PER_FRAME / launch_s / 1e9
+        per_gpu_fps = frames_per_step / launch_s
+        achieved = per_gpu_fps * BYTES_PER_FRAME / 1e9
+        sclk = (power or {}).get("sclk_MHz") or SCLK_MAX_MHZ
+        n_simd = _capi.device_info()["compute_units"] * 4
+        slots_per_s = per_gpu_fps * VALU_ISSUE_SLOTS_PER_FRAME
+        valu = {
+            "issue_slots_per_frame": VALU_ISSUE_SLOTS_PER_FRAME, "cycles_per_slot": CYCLES_PER_SLOT,
+            "achieved_slots_per_s": slots_per_s,
+            "peak_slots_per_s_at_sclk": n_simd * sclk * 1e6 / CYCLES_PER_SLOT, "sustained_clk_MHz": sclk,
+            "frac_at_sclk": slots_per_s / (n_simd * sclk * 1e6 / CYCLES_PER_SLOT),
+            "frac_at_2400MHz": slots_per_s / (n_simd * SCLK_MAX_MHZ * 1e6 / CYCLES_PER_SLOT),
+            "lane_ops_per_s": slots_per_s * 64, "peak_lane_ops_per_s": n_simd * 32 * sclk * 1e6,
+        }
+        hbm_frac = achieved / HBM_PEAK_GBS
         res = {
             "metric": "STFT frames/sec at n_fft=1024 hop=256, 48kHz mono; % HBM roofline",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed_max * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed_max * 1e3 / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"cfg2: {n_clips} clips x 10 s x 48 kHz f32 per GPU, n_fft=1024 hop=256 Hann, "
-                                   "detrend=constant, one-sided density PSD (linear power), inputs resident in HBM",
+            "config": {"workload": f"cfg2: {args.clips} clips x 10 s x 48 kHz f32 "
+                                   f"{'per GPU' if args.scaling == 'weak' else 'in all, sharded over the ranks'}, "
+                                   "n_fft=1024 hop=256 Hann, detrend=constant, one-sided density PSD (linear power), "
+                                   "inputs resident in HBM",
                        "clips_per_gpu": n_clips, "frames_per_step_per_gpu": frames_per_step,
                        "sharding": "clips over ranks, no data-path collective", "kernel": plan.kernel,
                        "buffer_sets": N_BUFFER_SETS},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(),
+            # the nearer of the two throughput roofs is HBM (valu.frac_at_sclk is lower); what actually stops the kernel
+            # from running faster is the board power cap, reported in "power" / "limiter"
+            "roofline": {"bound": "hbm" if hbm_frac >= valu["frac_at_sclk"] else "valu",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": hbm_frac, "traffic": load_traffic(),
                          "kernel": "stft1024_r8x3_kernel", "us_per_launch": launch_s * 1e6,
                          "algorithmic_bytes_per_frame": BYTES_PER_FRAME,
-                         "read_only_frac": frames_per_step * HOP * 4 / launch_s / 1e9 / HBM_PEAK_GBS},
-            "pct_hbm_roofline": 100.0 * achieved / HBM_PEAK_GBS,
+                         "read_only_frac": per_gpu_fps * HOP * 4 / 1e9 / HBM_PEAK_GBS,
+                         "practical_hbm_GBs_for_this_mix": 5500.0,      # profiles/r02_ubench_hbm_peaks.txt: 1 read : 2 write
+                         "frac_of_practical": achieved / 5500.0,
+                         "valu": valu},
+            "fp32_flops": {"algorithmic_TFLOPs": per_gpu_fps * FLOP_PER_FRAME_ALGORITHMIC / 1e12,
+                           "executed_TFLOPs": per_gpu_fps * FLOP_PER_FRAME_EXECUTED / 1e12,
+                           "peak_TFLOPs": FP32_PEAK_TFLOPS, "flop_per_frame_algorithmic": FLOP_PER_FRAME_ALGORITHMIC,
+                           "flop_per_frame_executed": FLOP_PER_FRAME_EXECUTED,
+                           "frac_executed": per_gpu_fps * FLOP_PER_FRAME_EXECUTED / 1e12 / FP32_PEAK_TFLOPS},
+            "pct_hbm_roofline": 100.0 * hbm_frac,
         }
+        if power:
+            res["power"] = power
+            at_cap = bool(power.get("board_W") and power.get("cap_W") and power["board_W"] >= 0.97 * power["cap_W"])
+            res["limiter"] = ("board power cap: time = energy per launch / cap (DESIGN.md section 5)" if at_cap
+                              else "below the power cap")
+            if power.get("board_W"):
+                res["power"]["uJ_per_frame"] = power["board_W"] * power["us_per_launch_during_sample"] / max(frames_per_step, 1)
+        if gather:
+            res["gather"] = gather
         if world == 1 and not args.no_cpu_baseline:
             from oracle.cpu_baseline import time_cpu_baseline
             clips = (np.random.default_rng(1234).standard_normal((CLIPS_PER_GPU, N_SAMPLES)).astype(np.float32)
@@ -183,6 +330,45 @@ def main():
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def time_gather(args, plan, x, out, n_clips, n_frames, dev, same_gpu, world, rank, stream):
+    """The path's one exchange, timed OUTSIDE the throughput region: every rank reduces its shard to the per-frame band
+    power (fused kernel, [clips, frames] f32) and sends it to rank 0 by direct peer sends (spectro.dist.gather_to_root);
+    with --gather-full the full spectra [clips, frames, 513] go too.  -> dict for rank 0, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    from spectro import dist as sdist
+    band = torch.empty((max(n_clips, 1), n_frames), device=dev, dtype=torch.float32)
+    if n_clips:
+        plan.band_power(x.data_ptr(), N_SAMPLES, N_SAMPLES, n_clips, 0, N_BINS - 1, band.data_ptr(), n_frames, stream=stream)
+    torch.cuda.synchronize(dev)
+    res = {}
+    for name, tens in (("band_power", band[:n_clips]),) + ((("full_spectra", out[:n_clips]),) if args.gather_full else ()):
+        send = tens.cpu() if same_gpu else tens
+        shapes = [None] * world
+        dist.all_gather_object(shapes, [tuple(send.shape)])
+        best = None
+        for rep in range(3):
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            got = sdist.gather_to_root([send], dst=0, shapes=shapes)
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t0
+            tt = torch.tensor([dt], device="cpu" if same_gpu else dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            best = float(tt[0]) if best is None else min(best, float(tt[0]))
+        if rank == 0:
+            nbytes = sum(int(torch.tensor(s[0]).prod()) * 4 for r, s in enumerate(shapes) if r != 0)
+            ok = all(tuple(g[0].shape) == tuple(shapes[r][0]) for r, g in enumerate(got))
+            res[name] = {"gather_ms": best * 1e3, "bytes_to_root": nbytes, "gather_GBps": nbytes / best / 1e9 if best > 0 else None,
+                         "shapes_ok": ok}
+    if rank == 0:
+        res["note"] = ("after the timed region, best of 3, max over ranks; direct peer sends to rank 0 (xGMI is point-to-point, "
+                       "a one-shot gather is bounded by the root's inbound links)")
+        return res
+    return None
 
 
 if __name__ == "__main__":

@@ -66,6 +66,9 @@ int sg_device_count(int* count);
 int sg_init(int device);
 /* name (e.g. "gfx950"), CU count and HBM bytes of the current device */
 int sg_device_info(char* arch, size_t arch_len, int* compute_units, uint64_t* hbm_bytes);
+/* PCI address of the current device as sysfs spells it ("0000:05:00.0"): /sys/bus/pci/devices/<id>/hwmon/ holds its
+ * clock and board-power sensors, which bench.py reads beside the timing (the headline kernel runs at the power cap). */
+int sg_device_pci_bus_id(char* buf, size_t len /* >= 13 */);
 
 /* ---- raw device memory / streams (so a ctypes host needs nothing else) -- */
 int sg_malloc(void** dev_ptr, size_t bytes);
@@ -180,6 +183,9 @@ int sg_normalise_image(const void* spec_dev, int dtype, int64_t n_frames, int n_
 /* A11 (PlotEngine.py:239-241): feat[f] = (log10(p[f]+1e-20), diff with prepend) from band sums p. */
 int sg_band_features(const void* band_dev, int dtype, int64_t n_frames, void* feat_dev /* [n_frames][2] */,
                      void* stream);
+/* The same for n_clips clips of n_frames each in one launch (band_dev [n_clips][n_frames], feat_dev [n_clips][n_frames][2]):
+ * the difference restarts at every clip. */
+int sg_band_features_batch(const void* band_dev, int dtype, int n_clips, int64_t n_frames, void* feat_dev, void* stream);
 /* A11 without the fused kernel: p[f] = sum_{k_lo..k_hi} spec[f][k] */
 int sg_band_sum(const void* spec_dev, int dtype, int64_t n_frames, int n_bins, int k_lo, int k_hi,
                 void* band_dev, void* stream);

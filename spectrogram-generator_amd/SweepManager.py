@@ -148,14 +148,18 @@ class SweepManager:
         copied back (default: the full ``[clip, freq, time]`` PSD)."""
         from spectro import engine
         x, fs = self._stack(names, processed)
+        clips = engine.DeviceClips(x)                  # the clips cross PCIe once for all pairs
         out = {}
-        for n in n_ffts:
-            for h in hops:
-                dev = engine.stft(x, fs=fs, window=window, nperseg=n, noverlap=n - h)
-                try:
-                    out[(n, h)] = (dev.f, dev.t, dev.to_host() if reduce is None else reduce(dev))
-                finally:
-                    dev.free()
+        try:
+            for n in n_ffts:
+                for h in hops:
+                    dev = clips.stft(fs=fs, window=window, nperseg=n, hop=h)
+                    try:
+                        out[(n, h)] = (dev.f, dev.t, dev.to_host() if reduce is None else reduce(dev))
+                    finally:
+                        dev.free()
+        finally:
+            clips.free()
         return out
 
 

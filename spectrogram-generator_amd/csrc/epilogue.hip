@@ -202,12 +202,13 @@ __global__ __launch_bounds__(kThreads) void band_sum_kernel(const T* spec, int64
     }
 }
 
+// `per_clip` frames form one clip: the first difference does not reach across a clip boundary (diff(prepend=lp[0]))
 template <typename T>
-__global__ __launch_bounds__(kThreads) void band_features_kernel(const T* band, int64_t n_frames, T* feat) {
+__global__ __launch_bounds__(kThreads) void band_features_kernel(const T* band, int64_t n_frames, int64_t per_clip, T* feat) {
     for (int64_t f = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; f < n_frames;
          f += static_cast<int64_t>(gridDim.x) * kThreads) {
         const T lp = t_log10<T>(band[f] + T(1e-20));
-        const T lp_prev = f > 0 ? t_log10<T>(band[f - 1] + T(1e-20)) : lp;
+        const T lp_prev = (f % per_clip) > 0 ? t_log10<T>(band[f - 1] + T(1e-20)) : lp;
         feat[2 * f] = lp;
         feat[2 * f + 1] = lp - lp_prev;
     }
@@ -541,19 +542,24 @@ int sg_band_sum(const void* spec_dev, int dtype, int64_t n_frames, int n_bins, i
     return after_launch("band_sum");
 }
 
-int sg_band_features(const void* band_dev, int dtype, int64_t n_frames, void* feat_dev, void* stream) {
+int sg_band_features_batch(const void* band_dev, int dtype, int n_clips, int64_t n_frames, void* feat_dev, void* stream) {
     if (!band_dev || !feat_dev) { set_error("null pointer"); return SG_ERR_ARG; }
-    if (n_frames < 0) { set_error("n_frames < 0"); return SG_ERR_ARG; }
-    if (n_frames == 0) return SG_OK;
+    if (n_frames < 0 || n_clips < 0) { set_error("negative sizes"); return SG_ERR_ARG; }
+    const int64_t total = n_frames * n_clips;
+    if (total == 0) return SG_OK;
     auto s = static_cast<hipStream_t>(stream);
     if (dtype == SG_F32)
-        hipLaunchKernelGGL(band_features_kernel<float>, dim3(grid_for(n_frames)), dim3(kThreads), 0, s,
-                           static_cast<const float*>(band_dev), n_frames, static_cast<float*>(feat_dev));
+        hipLaunchKernelGGL(band_features_kernel<float>, dim3(grid_for(total)), dim3(kThreads), 0, s,
+                           static_cast<const float*>(band_dev), total, n_frames, static_cast<float*>(feat_dev));
     else if (dtype == SG_F64)
-        hipLaunchKernelGGL(band_features_kernel<double>, dim3(grid_for(n_frames)), dim3(kThreads), 0, s,
-                           static_cast<const double*>(band_dev), n_frames, static_cast<double*>(feat_dev));
+        hipLaunchKernelGGL(band_features_kernel<double>, dim3(grid_for(total)), dim3(kThreads), 0, s,
+                           static_cast<const double*>(band_dev), total, n_frames, static_cast<double*>(feat_dev));
     else { set_error("bad dtype %d", dtype); return SG_ERR_ARG; }
     return after_launch("band_features");
+}
+
+int sg_band_features(const void* band_dev, int dtype, int64_t n_frames, void* feat_dev, void* stream) {
+    return sg_band_features_batch(band_dev, dtype, 1, n_frames, feat_dev, stream);
 }
 
 int sg_band_totals(const void* spec_dev, int dtype, int64_t n_frames, int n_bins, int n_bands, const int* k_lo_host,

@@ -168,6 +168,15 @@ int sg_device_info(char* arch, size_t arch_len, int* compute_units, uint64_t* hb
     return SG_OK;
 }
 
+int sg_device_pci_bus_id(char* buf, size_t len) {
+    if (!buf || len < 13) { set_error("sg_device_pci_bus_id: buffer of at least 13 bytes needed"); return SG_ERR_ARG; }
+    int dev = 0;
+    SG_HIP(hipGetDevice(&dev));
+    SG_HIP(hipDeviceGetPCIBusId(buf, static_cast<int>(len), dev));
+    for (char* c = buf; *c; ++c) if (*c >= 'A' && *c <= 'F') *c = static_cast<char>(*c - 'A' + 'a');   // sysfs spells it in lower case
+    return SG_OK;
+}
+
 int sg_malloc(void** dev_ptr, size_t bytes) {
     if (!dev_ptr) { set_error("null pointer"); return SG_ERR_ARG; }
     SG_HIP(hipMalloc(dev_ptr, bytes ? bytes : 1));

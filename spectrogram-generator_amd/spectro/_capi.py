@@ -30,6 +30,7 @@ SIGNATURES = {
     "sg_device_count": (_i, [C.POINTER(_i)]),
     "sg_init": (_i, [_i]),
     "sg_device_info": (_i, [C.c_char_p, _sz, C.POINTER(_i), C.POINTER(C.c_uint64)]),
+    "sg_device_pci_bus_id": (_i, [C.c_char_p, _sz]),
     "sg_malloc": (_i, [_pvp, _sz]),
     "sg_free": (_i, [_vp]),
     "sg_host_alloc": (_i, [_pvp, _sz]),
@@ -62,6 +63,7 @@ SIGNATURES = {
     "sg_minmax": (_i, [_vp, _i, _i64, _i, _i, _i, _vp, _vp]),
     "sg_normalise_image": (_i, [_vp, _i, _i64, _i, _i, _i, _i, _d, _vp, _vp, _vp]),
     "sg_band_features": (_i, [_vp, _i, _i64, _vp, _vp]),
+    "sg_band_features_batch": (_i, [_vp, _i, _i, _i64, _vp, _vp]),
     "sg_band_sum": (_i, [_vp, _i, _i64, _i, _i, _i, _vp, _vp]),
     "sg_band_totals": (_i, [_vp, _i, _i64, _i, _i, C.POINTER(_i), C.POINTER(_i), _vp, _vp]),
     "sg_slice_bins": (_i, [_vp, _i, _i64, _i, _i, _i, _vp, _vp]),
@@ -135,6 +137,12 @@ def device_info():
     cu, mem = _i(0), C.c_uint64(0)
     check(lib().sg_device_info(buf, 64, C.byref(cu), C.byref(mem)))
     return {"arch": buf.value.decode(), "compute_units": cu.value, "hbm_bytes": mem.value}
+
+
+def device_pci_bus_id() -> str:
+    buf = C.create_string_buffer(32)
+    check(lib().sg_device_pci_bus_id(buf, 32))
+    return buf.value.decode()
 
 
 class DeviceBuffer:

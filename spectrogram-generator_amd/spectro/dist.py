@@ -28,6 +28,11 @@ def shard_range(n_items: int, world: int, rank: int):
     return start, start + base + (1 if rank < rem else 0)
 
 
+def n_frames(n_samples: int, n_fft: int, hop: int) -> int:
+    """A2: ``(N - n)//hop + 1`` frames, none when the clip is shorter than a frame (scipy:2180-2188)."""
+    return 0 if n_samples < n_fft else (n_samples - n_fft) // hop + 1
+
+
 def stft_cost(n_samples: int, n_fft: int, hop: int) -> float:
     """Relative cost of one (clip, n_fft, hop) work item: frames * n log n (BASELINE cfg4 balancing)."""
     frames = 0 if n_samples < n_fft else (n_samples - n_fft) // hop + 1
@@ -67,25 +72,48 @@ def global_max(local_max):
     return local_max
 
 
+def _backend():
+    d = _dist()
+    try:
+        return str(d.get_backend()).lower()
+    except Exception:
+        return ""
+
+
+def _comm_tensor(t):
+    """RCCL moves device memory only: under the "nccl" backend a host tensor is staged on this rank's GPU first
+    (gloo, the CPU tests' backend, takes host tensors as they are).  -> (tensor to communicate, came_from_host)"""
+    import torch
+    if "nccl" in _backend() and not t.is_cuda:
+        return t.to(torch.device("cuda", torch.cuda.current_device())), True
+    return t, False
+
+
 def gather_equal(t, dst: int | None = None):
-    """Gather equal-shaped tensors: all ranks get the list when ``dst`` is None, else only ``dst``."""
+    """Gather equal-shaped tensors, one per rank: all ranks get the list when ``dst`` is None, else only ``dst``
+    (the other ranks get None)."""
     import torch
     d = _dist()
     world, rank = world_info()
     if world == 1:
         return [t]
     if dst is None:
-        out = [torch.empty_like(t) for _ in range(world)]
-        d.all_gather(out, t.contiguous())
-        return out
-    return gather_to_root([t], dst)[0] if rank == dst else (gather_to_root([t], dst) or None)
+        ct, staged = _comm_tensor(t.contiguous())
+        out = [torch.empty_like(ct) for _ in range(world)]
+        d.all_gather(out, ct)
+        return [o.cpu() for o in out] if staged else out
+    parts = gather_to_root([t], dst, shapes=[[tuple(t.shape)]] * world)
+    return [parts[r][0] for r in range(world)] if rank == dst else None
 
 
 def gather_to_root(tensors, dst: int = 0, shapes=None):
     """Ragged gather by direct peer sends (RCCL has no gatherv): every rank sends its tensors to ``dst``.
 
     ``shapes[r]`` lists the shapes rank ``r`` sends; when None they are exchanged first with
-    ``all_gather_object``.  Returns on ``dst`` a list (per rank) of lists of tensors, elsewhere None."""
+    ``all_gather_object``.  The sends and receives of a rank are posted as ONE batch (``batch_isend_irecv``), so under
+    RCCL the root's seven inbound xGMI links carry their shards concurrently instead of one peer after the other.
+    Host tensors are staged through the rank's GPU when the backend is RCCL and come back as host tensors.
+    Returns on ``dst`` a list (per rank) of lists of tensors, elsewhere None."""
     import torch
     d = _dist()
     world, rank = world_info()
@@ -94,21 +122,37 @@ def gather_to_root(tensors, dst: int = 0, shapes=None):
     if shapes is None:
         shapes = [None] * world
         d.all_gather_object(shapes, [tuple(t.shape) for t in tensors])
+    staged_any = False
+    comm = []
+    for t in tensors:
+        ct, staged = _comm_tensor(t.contiguous())
+        staged_any |= staged
+        comm.append(ct)
     if rank == dst:
-        out, reqs = [], []
+        dtype = comm[0].dtype if comm else torch.float32
+        if comm:
+            device = comm[0].device
+        else:
+            device = torch.device("cuda", torch.cuda.current_device()) if "nccl" in _backend() else torch.device("cpu")
+            staged_any = "nccl" in _backend()
+        out, ops = [], []
         for r in range(world):
             if r == dst:
                 out.append(list(tensors))
                 continue
-            bufs = [torch.empty(s, dtype=tensors[0].dtype if tensors else torch.float32,
-                                device=tensors[0].device if tensors else "cpu") for s in shapes[r]]
-            reqs += [d.irecv(b, src=r) for b in bufs]
+            bufs = [torch.empty(s, dtype=dtype, device=device) for s in shapes[r]]
+            ops += [d.P2POp(d.irecv, b, r) for b in bufs if b.numel()]
             out.append(bufs)
-        for q in reqs:
-            q.wait()
+        if ops:
+            for q in d.batch_isend_irecv(ops):
+                q.wait()
+        if staged_any:
+            out = [part if r == dst else [b.cpu() for b in part] for r, part in enumerate(out)]
         return out
-    for q in [d.isend(t.contiguous(), dst=dst) for t in tensors]:
-        q.wait()
+    ops = [d.P2POp(d.isend, t, dst) for t in comm if t.numel()]
+    if ops:
+        for q in d.batch_isend_irecv(ops):
+            q.wait()
     return None
 
 

@@ -20,7 +20,7 @@ import numpy as np
 from . import _capi
 from .signal import compute_dtype, plan_for, resolve_segments
 
-__all__ = ["DeviceSpectrogram", "stft", "band_features", "bin_range"]
+__all__ = ["DeviceSpectrogram", "DeviceClips", "stft", "band_features", "log_image", "bin_range"]
 
 
 def bin_range(f: np.ndarray, fmin: float, fmax: float):
@@ -175,10 +175,9 @@ def _features_from_band(band, dtype_code, n_clips, n_frames):
     if feats.size:
         d = _capi.DeviceBuffer(feats.nbytes)
         try:
-            isz = np.dtype(dt).itemsize
-            for c in range(n_clips):          # the diff must not cross clip boundaries
-                _capi.check(_capi.lib().sg_band_features(C.c_void_p(band.ptr + c * n_frames * isz), dtype_code, n_frames,
-                                                         C.c_void_p(d.ptr + c * n_frames * 2 * isz), None))
+            # one launch for the batch; the diff restarts at every clip
+            _capi.check(_capi.lib().sg_band_features_batch(C.c_void_p(band.ptr), dtype_code, n_clips, n_frames,
+                                                           C.c_void_p(d.ptr), None))
             d.download(feats)
             _capi.stream_sync()
         finally:
@@ -279,3 +278,176 @@ def band_features(x, fs, nperseg, fmin, fmax, window=("tukey", .25), noverlap=No
         d_in.free()
         band.free()
     return t, feats.reshape(*outer, n_frames, 2)
+
+
+class DeviceClips:
+    """A batch of equal-length clips ``[n_clips, n_samples]`` uploaded ONCE and kept in HBM (f32, f64 or int16 PCM), so
+    that a parameter sweep (BASELINE cfg4: 15 (n_fft, hop) pairs over the same clips) or several products of one batch
+    do not cross PCIe again per call."""
+
+    def __init__(self, x):
+        x = np.asarray(x)
+        if x.ndim == 1:
+            x = x[None]
+        if x.ndim != 2:
+            raise ValueError("DeviceClips takes [n_clips, n_samples]")
+        if np.iscomplexobj(x):
+            raise NotImplementedError("complex input is outside the device path")
+        self.int16 = x.dtype == np.int16
+        self.cdt = compute_dtype(x.dtype)
+        self.code = _capi.F32 if self.cdt == np.float32 else _capi.F64
+        xh = np.ascontiguousarray(x, dtype=np.int16 if self.int16 else self.cdt)
+        self.n_clips, self.n_samples = xh.shape
+        _capi.ensure_device()
+        self.buf = _capi.DeviceBuffer(max(xh.nbytes, 8))
+        self.buf.upload(xh)
+        _capi.stream_sync()
+        self._f = None      # float copy of int16 clips for the kernels that take no int16 (made on first need)
+
+    def free(self):
+        for b in (self.buf, self._f):
+            if b is not None:
+                b.free()
+        self.buf = self._f = None
+
+    def _plan(self, fs, window, nperseg, hop, detrend, nfft=None, scaling="density", mode="psd"):
+        win, nperseg = resolve_segments(window, nperseg, input_length=self.n_samples)
+        if hop is None:
+            hop = nperseg - nperseg // 8
+        if not (1 <= hop <= nperseg):
+            raise ValueError("noverlap must be less than nperseg.")
+        if detrend not in _capi.DETREND:
+            raise ValueError("Trend type must be 'linear' or 'constant'.")
+        nfft = nperseg if nfft is None else int(nfft)
+        return plan_for(win, nperseg, nfft, int(hop), _capi.DETREND[detrend], fs, _capi.SCALING[scaling], _capi.MODE[mode],
+                        self.code), nperseg, int(hop), nfft
+
+    def _float_ptr(self):
+        """device pointer of the clips as the plan's float type (int16 batches: converted once, on the host side of PCIe
+        only if a kernel without an int16 front end asks for it)"""
+        if not self.int16:
+            return self.buf.ptr
+        if self._f is None:
+            raw = np.empty((self.n_clips, self.n_samples), np.int16)
+            self.buf.download(raw)
+            _capi.stream_sync()
+            self._f = _capi.DeviceBuffer(max(raw.size * 4, 8))
+            self._f.upload(raw.astype(np.float32))
+            _capi.stream_sync()
+        return self._f.ptr
+
+    def stft(self, fs=1.0, window=("tukey", .25), nperseg=None, hop=None, detrend="constant", scaling="density",
+             mode="psd", nfft=None) -> DeviceSpectrogram:
+        if mode not in ("psd", "magnitude"):
+            raise ValueError("mode must be 'psd' or 'magnitude'")
+        plan, nperseg, hop, nfft = self._plan(fs, window, nperseg, hop, detrend, nfft, scaling, mode)
+        n_frames, n_bins = plan.n_frames(self.n_samples), plan.n_bins
+        isz = np.dtype(self.cdt).itemsize
+        out = _capi.DeviceBuffer(max(self.n_clips * n_frames * n_bins * isz, 8))
+        i16 = self.int16 and plan.kernel != "bluestein"
+        plan.stft(self.buf.ptr if i16 else self._float_ptr(), self.n_samples, self.n_samples, self.n_clips, out.ptr,
+                  n_frames * n_bins, int16=i16)
+        return DeviceSpectrogram(out, self.code, self.n_clips, n_frames, n_bins, _capi.freqs(nfft, fs),
+                                 _capi.times(self.n_samples, nperseg, hop, fs), fs, plan, (self.n_clips,))
+
+    def band_log_power(self, fs, nperseg, hop, fmin, fmax, window=("tukey", .25), detrend="constant", clip_range=None):
+        """A11 for the whole batch (or clips ``clip_range = (a, b)`` of it) in two launches: fused band power (the spectra
+        never reach HBM) and log10 / first difference.  -> ``(t, feats[n_clips, n_frames, 2])``; ``(None, None)`` without frames."""
+        plan, nperseg, hop, nfft = self._plan(fs, window, nperseg, hop, detrend)
+        n_frames = plan.n_frames(self.n_samples)
+        a, b = (0, self.n_clips) if clip_range is None else (int(clip_range[0]), int(clip_range[1]))
+        if not (0 <= a <= b <= self.n_clips):
+            raise ValueError("clip_range outside the batch")
+        if n_frames == 0 or b == a:
+            return None, None
+        return self._band_log_power(plan, nperseg, hop, nfft, fs, fmin, fmax, n_frames, a, b - a)
+
+    def _band_log_power(self, plan, nperseg, hop, nfft, fs, fmin, fmax, n_frames, first, count):
+        view = _ClipView(self, first, count)
+        return view.band_log_power(plan, nperseg, hop, nfft, fs, fmin, fmax, n_frames)
+    def log_image(self, fs, nperseg, hop, fmin, fmax, global_max, window=("tukey", .25), detrend="constant", rescale=True):
+        """The log display of PlotEngine.py:126-131 for a caller-supplied ``global_max`` (:110), per batch:
+        ``(f_band, t, image[n_clips, n_band, n_frames])`` with the min-max taken over the whole batch.
+
+        nperseg = nfft = 1024 f32 plans run the fused kernel (``sg_stft_db``: the linear spectrum never reaches HBM and
+        the extrema come out of the same launch); every other plan composes ``sg_stft`` + ``sg_normalise_image``."""
+        if global_max is None or not (global_max > 0):
+            raise ValueError("log_image needs the batch-global base: global_max > 0")
+        plan, nperseg, hop, nfft = self._plan(fs, window, nperseg, hop, detrend)
+        n_frames = plan.n_frames(self.n_samples)
+        f = _capi.freqs(nfft, fs)
+        t = _capi.times(self.n_samples, nperseg, hop, fs)
+        k_lo, k_hi = bin_range(f, fmin, fmax)
+        width = max(k_hi - k_lo + 1, 0)
+        img = np.empty((self.n_clips, n_frames, width), self.cdt)
+        if img.size == 0:
+            return f[k_lo:k_hi + 1], t, np.moveaxis(img, -1, -2)
+        if plan.kernel == "r8x3" and plan.mode == _capi.MODE["psd"]:
+            d_img, mm = _capi.DeviceBuffer(img.nbytes), _capi.DeviceBuffer(8)
+            try:
+                plan.stft_db(self._float_ptr(), self.n_samples, self.n_samples, self.n_clips, k_lo, k_hi, float(global_max),
+                             d_img.ptr, n_frames * width, mm.ptr)
+                if rescale:
+                    _capi.check(_capi.lib().sg_db_rescale(C.c_void_p(d_img.ptr), img.size, C.c_void_p(mm.ptr), None))
+                d_img.download(img)
+                _capi.stream_sync()
+            finally:
+                d_img.free()
+                mm.free()
+        else:
+            if not rescale:
+                raise NotImplementedError("the un-rescaled dB image is a product of the fused kernel only")
+            dev = self.stft(fs, window, nperseg, hop, detrend)
+            try:
+                return f[k_lo:k_hi + 1], t, dev.image(k_lo, k_hi, True, global_max)      # [n_clips, n_band, n_frames]
+            finally:
+                dev.free()
+        return f[k_lo:k_hi + 1], t, np.moveaxis(img, -1, -2)
+
+
+class _ClipView:
+    """clips ``first .. first + count`` of a ``DeviceClips`` (a pointer offset: clips are rows of one buffer)"""
+
+    def __init__(self, clips: "DeviceClips", first: int, count: int):
+        self.count, self.n_samples, self.cdt, self.code = count, clips.n_samples, clips.cdt, clips.code
+        self.ptr = clips._float_ptr() + first * clips.n_samples * np.dtype(clips.cdt).itemsize
+
+    def band_log_power(self, plan, nperseg, hop, nfft, fs, fmin, fmax, n_frames):
+        f = _capi.freqs(nfft, fs)
+        t = _capi.times(self.n_samples, nperseg, hop, fs)
+        k_lo, k_hi = bin_range(f, fmin, fmax)
+        if k_lo > k_hi:
+            feats = np.zeros((self.count, n_frames, 2), self.cdt)
+            feats[..., 0] = np.log10(self.cdt(0) + 1e-20)
+            return t, feats
+        isz = np.dtype(self.cdt).itemsize
+        band = _capi.DeviceBuffer(self.count * n_frames * isz)
+        try:
+            if plan.kernel == "bluestein":
+                spec = _capi.DeviceBuffer(self.count * n_frames * plan.n_bins * isz)
+                try:
+                    plan.stft(self.ptr, self.n_samples, self.n_samples, self.count, spec.ptr, n_frames * plan.n_bins)
+                    _capi.check(_capi.lib().sg_band_sum(C.c_void_p(spec.ptr), self.code, self.count * n_frames, plan.n_bins,
+                                                        k_lo, k_hi, C.c_void_p(band.ptr), None))
+                    _capi.stream_sync()
+                finally:
+                    spec.free()
+            else:
+                plan.band_power(self.ptr, self.n_samples, self.n_samples, self.count, k_lo, k_hi, band.ptr, n_frames)
+            return t, _features_from_band(band, self.code, self.count, n_frames)
+        finally:
+            band.free()
+
+
+def log_image(x, fs, nperseg, fmin, fmax, global_max, window=("tukey", .25), noverlap=None, detrend="constant"):
+    """One-call form of ``DeviceClips.log_image`` for a host array ``[..., n_samples]`` -> ``(f_band, t, image[..., n_band, n_frames])``."""
+    x = np.asarray(x)
+    outer = x.shape[:-1]
+    clips = DeviceClips(x.reshape(-1, x.shape[-1]))
+    try:
+        win, nperseg = resolve_segments(window, nperseg, input_length=x.shape[-1])
+        hop = nperseg - (nperseg // 8 if noverlap is None else int(noverlap))
+        f, t, img = clips.log_image(fs, nperseg, hop, fmin, fmax, global_max, window=win, detrend=detrend)
+    finally:
+        clips.free()
+    return f, t, img.reshape(*outer, *img.shape[1:])

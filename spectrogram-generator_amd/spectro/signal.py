@@ -67,7 +67,9 @@ def plan_for(win, nperseg, nfft, hop, detrend, fs, scaling, mode, dtype):
         p = _capi.Plan(nperseg, nfft, hop, w, detrend, fs, scaling, mode, dtype)
         _plan_cache[key] = p
         while len(_plan_cache) > _PLAN_CACHE_MAX:
-            _plan_cache.popitem(last=False)[1].close()
+            # drop the entry only: a StreamingSTFT / DeviceSpectrogram / caller of plan_for may still hold the Plan, whose
+            # __del__ frees the device tables when the last reference goes
+            _plan_cache.popitem(last=False)
     else:
         _plan_cache.move_to_end(key)
     return p

@@ -263,6 +263,12 @@ GLOO_SCRIPT = textwrap.dedent('''
         assert gathered is None
         eq = sd.gather_equal(torch.full((2,), float(rank)))
     assert [float(e[0]) for e in eq] == [0.0, 1.0]
+    # gather_equal to ONE rank: that rank gets one tensor per rank, in rank order; the others get None
+    only1 = sd.gather_equal(torch.full((3,), float(10 + rank)), dst=1)
+    if rank == 1:
+        assert len(only1) == 2 and [float(e[0]) for e in only1] == [10.0, 11.0] and all(e.shape == (3,) for e in only1)
+    else:
+        assert only1 is None
     # cfg4: sharded parameter sweep; the per-item "device call" is the oracle here (no GPU in this container)
     from spectro import sweep
     clips = (np.random.default_rng(9).standard_normal((3, 4000)) * 0.1).astype(np.float32)
@@ -276,6 +282,29 @@ GLOO_SCRIPT = textwrap.dedent('''
             assert np.array_equal(v, item(clip, n, h)), (clip, n, h)
     else:
         assert res is None
+    # the batched deal (contiguous clip ranges per pair, one upload per rank, one call per pair) equals the per-item one;
+    # the oracle stands in for DeviceClips here and counts its calls
+    calls = {"open": 0, "run": 0}
+    def open_batch(xs):
+        calls["open"] += 1
+        def run(n, h, a, b):
+            calls["run"] += 1
+            f, t, s = orc.spectrogram(xs[a:b], fs=8000.0, nperseg=n, window="hann", noverlap=n - h)
+            return np.log10(s.sum(axis=-2) + 1e-20).astype(np.float32)          # [clip, frame]
+        return run
+    blocks = sweep.clip_blocks(3, [128, 256, 512], [32, 64], 2)
+    for pair, ranges in blocks.items():
+        assert ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][1] == 3
+    sizes = [sum(r[k][1] - r[k][0] for r in blocks.values()) for k in (0, 1)]
+    assert sizes[0] == sizes[1] == 9                                              # 6 pairs x 3 clips, the odd clip alternates
+    res_b = sweep.sharded_sweep(clips, 8000.0, [128, 256, 512], [32, 64], batch_compute=open_batch, dst=0)
+    assert calls["open"] == 1 and calls["run"] == 6                               # NOT one call per (clip, pair)
+    if rank == 0:
+        assert res_b.keys() == res.keys()
+        for k in res:
+            assert np.array_equal(res_b[k], res[k]), k
+    else:
+        assert res_b is None
     dist.barrier(); dist.destroy_process_group()
     os.write(1, ("rank %d ok" % rank + chr(10)).encode())   # one write per rank: print() pieces of two ranks can interleave
 ''')
@@ -295,6 +324,7 @@ def test_gloo_world2_sharding(tmp_path):
                            capture_output=True, text=True, timeout=300, env=env)
         if r.returncode == 0:
             break
+        print(f"[gloo test] attempt {attempt} failed (rc {r.returncode}); stderr tail:\n{r.stderr[-1500:]}", file=sys.stderr)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
 
