@@ -36,7 +36,8 @@
 extern "C" {
 #endif
 
-#define SG_VERSION 100 /* 0.1.0 */
+#define SG_VERSION 101 /* 0.1.1: sg_stft_mel takes weights_n_bins; sg_stft_db, sg_db_rescale, sg_colormap_db,
+                          * sg_band_features_batch, sg_device_pci_bus_id added */
 
 typedef enum sg_status {
     SG_OK = 0,
@@ -234,11 +235,13 @@ int sg_mel(const float* spec_dev, int64_t n_frames, int n_bins, const float* wei
  * BASELINE cfg3 fused: framing .. PSD as in sg_stft, then the mel contraction as an MFMA epilogue inside the same
  * kernel; only mel_dev[n_clips][n_frames][n_mels] is written (hop*4 + n_mels*4 algorithmic bytes per frame).
  * Needs an f32 nperseg = nfft = 1024 PSD plan (sg_plan_kernel == "r8x3"), an even hop and 8-byte aligned float input;
- * SG_ERR_UNSUPPORTED otherwise (use sg_stft + sg_mel).  Weights/ranges as for sg_mel.  Asynchronous.
+ * SG_ERR_UNSUPPORTED otherwise (use sg_stft + sg_mel).  Weights/ranges as for sg_mel; weights_n_bins is the n_bins the
+ * bank was packed for (sg_mel_pack_weights) and must equal the plan's nfft/2+1 (SG_ERR_ARG otherwise: the kernel indexes
+ * the bank with the plan's row pitch).  Asynchronous.
  */
 int sg_stft_mel(const sg_plan* plan, const float* x_dev, int64_t n_samples, int64_t clip_stride, int n_clips,
-                const float* packed_weights_dev, int n_mels, const int* tile_k_lo, const int* tile_k_hi,
-                int log_scale, float* mel_dev, int64_t out_clip_stride, void* stream);
+                const float* packed_weights_dev, int weights_n_bins, int n_mels, const int* tile_k_lo,
+                const int* tile_k_hi, int log_scale, float* mel_dev, int64_t out_clip_stride, void* stream);
 
 /* ---- timing helper used by bench.py (HIP events on `stream`) ---------- */
 /* Runs sg_stft `iters` times back to back between two hipEvents and returns the

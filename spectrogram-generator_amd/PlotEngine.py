@@ -9,9 +9,11 @@ attributes GUI.py / ExportManager.py read.  What changed is *where
   band sum / log10 / diff        (:232-242)        spectro.engine.band_features (fused, no spectrum in HBM)
   np.sum / band ratios           (:686-719)        DeviceSpectrogram.band_totals
 
-matplotlib only draws.  HMM burst detection (PlotEngine.py:244-478) and the mouse ROI editor
-(:480-667) are outside the accelerated path: the detectors are kept as thin wrappers
-that need ``hmmlearn`` at call time, the ROI editor keeps its state fields but wires no handlers.
+matplotlib only draws.  HMM burst detection (PlotEngine.py:244-478) is outside the accelerated path but on
+the drop-in surface: ``unsupervised_detect`` / ``learn_and_detect`` keep the reference's behaviour around the model
+(features from the device, post-fit transition surgery, supervised re-estimation, event extraction) and need
+``hmmlearn`` at call time.  The mouse ROI editor (:480-667) keeps its state fields; handlers are wired by
+``set_editing_enabled``.
 """
 from __future__ import annotations
 
@@ -65,7 +67,7 @@ class PlotEngine(_Canvas):
         self.segment_map = []
         self.currently_plotted_items = []
         self.burst_patches = []
-        # ROI editor state (handlers not wired: out of scope)
+        # ROI editor state
         self.editing_enabled = False
         self.hovered_patch = None
         self.is_adding = False
@@ -316,6 +318,20 @@ class PlotEngine(_Canvas):
                 merged.append((start, end))
         return merged
 
+    @staticmethod
+    def _open_escape_routes(model):
+        """After an unsupervised fit (PlotEngine.py:422-438): a non-baseline state that cannot reach the baseline state
+        (transition probability < 1e-5) donates 5 % of its self-transition, at most 0.05, to that transition -- provided
+        its self-transition exceeds 0.1 -- so a burst state can always end.  Baseline = lowest mean log-power."""
+        quiet = int(np.argmin(np.asarray(model.means_)[:, 0]))
+        trans = np.array(model.transmat_, dtype=float, copy=True)
+        for s in range(model.n_components):
+            if s != quiet and trans[s, quiet] < 1e-5 and trans[s, s] > 0.1:
+                gift = min(0.05 * trans[s, s], 0.05)
+                trans[s, s] -= gift
+                trans[s, quiet] += gift
+        model.transmat_ = trans
+
     def unsupervised_detect(self):
         if self.spec_data_source is None:
             raise ValueError("Please plot a spectrogram before detecting.")
@@ -323,14 +339,19 @@ class PlotEngine(_Canvas):
         if t is None or len(t) == 0:
             return []
         model = self._need_model()
-        feats = np.asarray(feats, np.float64)
         if not self.is_model_refined:
             if len(feats) < model.n_components:
                 raise ValueError("Not enough data to train the model. Signal may be too short.")
             model.fit(feats)
-        states = model.predict(feats)
-        quiet = int(np.argmin(np.asarray(model.means_)[:, 0]))
+            self._open_escape_routes(model)
+        states = np.asarray(model.predict(feats))
+        means = np.asarray(model.means_)
+        if means.ndim != 2:
+            raise TypeError(f"HMM means has unexpected dimension: {means.ndim}. Expected 2.")
+        quiet = int(np.argmin(means[:, 0]))
         active = states != quiet
+        # an event opens at the last baseline frame before activity and closes at the last active frame
+        # (PlotEngine.py:447-470); one still open at the end of the signal closes at t[-1]
         events, start = [], None
         for i in range(1, len(states)):
             if start is None and not active[i - 1] and active[i]:
@@ -344,19 +365,250 @@ class PlotEngine(_Canvas):
         self.last_detected_events = self._merge_overlapping_events(events)
         return self.last_detected_events
 
+    def _find_burst_in_roi(self, roi_feats, roi_t):
+        """Inside one hand-drawn region: a fresh 2-state model, the state with the higher mean log-power is the burst,
+        its first and last frame are the burst's extent (PlotEngine.py:389-409)."""
+        model = self._need_model()
+        if len(roi_feats) < model.n_components:
+            return None
+        from hmmlearn import hmm
+        import warnings
+        local = hmm.GaussianHMM(n_components=2, covariance_type="diag", n_iter=50, random_state=42)
+        try:
+            with warnings.catch_warnings():
+                warnings.filterwarnings("ignore", category=UserWarning, module="hmmlearn")
+                local.fit(roi_feats)
+        except ValueError:
+            return None
+        means = np.asarray(local.means_)
+        if means.ndim != 2:
+            raise TypeError(f"HMM means has unexpected dimension: {means.ndim}. Expected 2.")
+        hits = np.where(np.asarray(local.predict(roi_feats)) == int(np.argmax(means[:, 0])))[0]
+        if len(hits) == 0:
+            return None
+        return roi_t[hits[0]], roi_t[hits[-1]]
+
+    def _train_supervised(self, feats, labels):
+        """Model parameters from labelled frames (PlotEngine.py:329-387): per state mean / variance (+1e-6; a single frame
+        gives variance 1e-6, no frame gives mean 0), transition counts normalised per row (a row without counts
+        becomes a pure self-transition), state 3 ("falling edge") always returns to state 0, start in state 0."""
+        model = self._need_model()
+        k, dim = model.n_components, feats.shape[1]
+        means, variances = np.zeros((k, dim)), np.full((k, dim), 1e-6)
+        for s in range(k):
+            rows = feats[labels == s]
+            if len(rows) > 1:
+                means[s], variances[s] = rows.mean(axis=0), rows.var(axis=0) + 1e-6
+            elif len(rows) == 1:
+                means[s] = rows[0]
+        model.means_, model.covars_ = means, variances
+        counts = np.zeros((k, k))
+        np.add.at(counts, (labels[:-1], labels[1:]), 1.0)
+        totals = counts.sum(axis=1, keepdims=True)
+        trans = np.divide(counts, totals, out=np.zeros_like(counts), where=totals != 0)
+        for s in np.where(totals.ravel() == 0)[0]:
+            trans[s, s] = 1.0
+        if k > 3:
+            trans[3, :] = 0.0
+            trans[3, 0] = 1.0
+        model.transmat_ = trans
+        model.startprob_ = np.array([1.0] + [0.0] * (k - 1)) if k == 4 else np.eye(k)[0]
+        self.is_model_refined = True
+
     def learn_and_detect(self):
+        """Supervised refinement from the hand-drawn regions (PlotEngine.py:244-327): each region is narrowed to its burst
+        by a local 2-state model, frames are labelled 0 baseline / 1 rising edge / 2 burst / 3 falling edge, the 4-state
+        model is re-estimated from the labels and decoded over the whole signal; an event runs from the first frame in
+        state 1 or 2 to the next frame in state 0."""
         if self.spec_data_source is None:
             raise ValueError("Please plot a spectrogram before learning.")
         if not self.burst_patches:
             raise ValueError("No manual regions provided to learn from.")
-        self._need_model()
-        raise NotImplementedError("supervised HMM refinement is outside the accelerated path (SURVEY §2)")
+        t, feats = self._calculate_features(self.spec_data_source, self.last_fs, self.last_settings)
+        if t is None:
+            return []
+        feats = np.asarray(feats)
+        bursts = []
+        for pair in self.burst_patches:
+            try:
+                lo, hi = pair[0].event_data
+            except AttributeError:                                  # spans drawn by older code carry no exact times
+                box = pair[0].get_extents()
+                lo, hi = box.x0, box.x1
+            inside = np.where((t >= lo) & (t <= hi))[0]
+            if len(inside) < 2:
+                continue
+            found = self._find_burst_in_roi(feats[inside, :], t[inside])
+            if found:
+                bursts.append(found)
+        if not bursts:
+            raise ValueError("Could not identify a clear burst in any of the provided regions.")
+        labels = np.zeros(len(t), dtype=int)
+        for b0, b1 in bursts:
+            i0, i1 = np.searchsorted(t, b0), np.searchsorted(t, b1)
+            if i0 >= i1:
+                continue
+            labels[i0] = 1
+            if i1 > i0 + 1:
+                labels[i0 + 1:i1] = 2
+            if i1 < len(labels):
+                labels[i1] = 3
+        self._train_supervised(feats, labels)
+        states = np.asarray(self.model.predict(feats))
+        events, start = [], None
+        for i, st in enumerate(states):
+            if start is None and st in (1, 2):
+                start = t[i]
+            elif start is not None and st == 0:
+                if t[i] > start:
+                    events.append((start, t[i]))
+                start = None
+        if start is not None:
+            events.append((start, t[-1]))
+        self.last_detected_events = self._merge_overlapping_events(events)
+        return self.last_detected_events
 
-    # ------------------------------------------------------------------ ROI patches
+    # ------------------------------------------------------------------ ROI patches (mouse editor, PlotEngine.py:480-667)
     def set_editing_enabled(self, enabled):
-        self.editing_enabled = bool(enabled)
-        self.is_adding = False
-        self.adding_patch = self.press_x = self.hovered_patch = None
+        """(Dis)connect the three mouse callbacks; a fresh start either way (GUI.py:315,434,447)."""
+        for attr in ("press_cid", "release_cid", "motion_cid"):
+            cid = getattr(self, attr)
+            if cid:
+                self.fig.canvas.mpl_disconnect(cid)
+            setattr(self, attr, None)
+        self.is_adding = self.adding_patch = self.press_x = self.hovered_patch = None
+        self.editing_enabled = enabled
+        if enabled:
+            connect = self.fig.canvas.mpl_connect
+            self.press_cid = connect("button_press_event", self.on_press)
+            self.release_cid = connect("button_release_event", self.on_release)
+            self.motion_cid = connect("motion_notify_event", self.on_motion)
+
+    @staticmethod
+    def _get_correct_xdata(event):
+        """Data-space x of a mouse event; falls back to the inverse axes transform of the pixel position."""
+        ax = event.inaxes
+        if ax is None:
+            return None
+        if event.xdata is not None:
+            return event.xdata
+        try:
+            return ax.transData.inverted().transform((event.x, event.y))[0]
+        except Exception:
+            return None
+
+    def _on_axes(self, event):
+        return self.editing_enabled and event.inaxes in (self.ax_signal, self.ax_spec) and event.xdata is not None
+
+    def _paint(self, pair, colour):
+        for patch in pair:
+            patch.set_color(colour)
+
+    def _drop_rubber_band(self):
+        if self.adding_patch:
+            for patch in self.adding_patch:
+                patch.remove()
+        self.adding_patch = None
+
+    def _span_pair(self, x0, x1, **style):
+        return tuple(ax.axvspan(x0, x1, **style) for ax in (self.ax_signal, self.ax_spec))
+
+    def on_motion(self, event):
+        if not self._on_axes(event):
+            if self.hovered_patch:                      # the pointer left the axes: un-highlight
+                self._paint(self.hovered_patch, self.ROI_COLOR)
+                self.hovered_patch = None
+                self._redraw()
+            return
+        x = self._get_correct_xdata(event)
+        if x is None:
+            return
+        if self.is_adding and self.press_x is not None:  # rubber band of the region being drawn
+            self._drop_rubber_band()
+            self.adding_patch = self._span_pair(self.press_x, x, color="green", alpha=0.3, zorder=5)
+            self._redraw()
+            return
+        which = 0 if event.inaxes is self.ax_signal else 1
+        under = next((pair for pair in self.burst_patches if pair[which].contains(event)[0]), None)
+        if under is not self.hovered_patch:
+            if self.hovered_patch:
+                self._paint(self.hovered_patch, self.ROI_COLOR)
+            if under:
+                self._paint(under, self.HOVER_COLOR)
+            self.hovered_patch = under
+            self._redraw()
+
+    def delete_hovered(self):
+        """Context-menu "Delete" on the highlighted region."""
+        if self.hovered_patch:
+            self.remove_patch(self.hovered_patch)
+            self.hovered_patch = None
+
+    def merge_into_hovered(self):
+        """Context-menu "Merge": the regions lying inside the highlighted one are replaced, together with it, by one event
+        from the earliest start to the latest end of the contained ones (exact times come from ``event_data``)."""
+        box = self.hovered_patch
+        if not box:
+            return
+        outer = box[0].get_extents()
+        inner = [pair for pair in self.burst_patches if pair is not box
+                 and pair[0].get_extents().x0 >= outer.x0 and pair[0].get_extents().x1 <= outer.x1]
+        if not inner:
+            return
+        gone = {pair[0].event_data for pair in inner + [box]}
+        merged = (min(pair[0].event_data[0] for pair in inner), max(pair[0].event_data[1] for pair in inner))
+        self.last_detected_events = sorted([ev for ev in self.last_detected_events if ev not in gone] + [merged])
+        self.plot_detection_lines(self.last_detected_events)
+        self.hovered_patch = None
+        self._redraw()
+
+    def on_press(self, event):
+        if not self._on_axes(event):
+            return
+        x = self._get_correct_xdata(event)
+        if x is None:
+            return
+        if event.button == 3 and self.hovered_patch:
+            choice = self._context_menu()
+            if choice == "Delete":
+                self.delete_hovered()
+            elif choice == "Merge":
+                self.merge_into_hovered()
+                return
+        if event.button == 1:
+            self.is_adding, self.press_x = True, x
+
+    def _context_menu(self):
+        """Qt pop-up with "Delete" / "Merge" at the cursor; None without Qt (headless canvas) or when dismissed."""
+        try:
+            from PyQt5 import QtWidgets
+            from PyQt5.QtGui import QCursor
+            menu = QtWidgets.QMenu(self.parent())
+        except Exception:
+            return None
+        delete, merge = menu.addAction("Delete"), menu.addAction("Merge")
+        chosen = menu.exec_(QCursor.pos())
+        return "Delete" if chosen == delete else "Merge" if chosen == merge else None
+
+    def on_release(self, event):
+        x = self._get_correct_xdata(event)
+        if not self.editing_enabled or not self.is_adding or x is None:
+            self._drop_rubber_band()
+            self.is_adding = self.press_x = None
+            return
+        self._drop_rubber_band()
+        if hasattr(self, "last_raw_t") and len(self.last_raw_t) > 1:
+            narrowest = self.last_raw_t[1] - self.last_raw_t[0]        # one sample
+        else:
+            narrowest = 1.0 / self.last_fs if self.last_fs else 0.01
+        if abs(self.press_x - x) >= narrowest:
+            span = (min(self.press_x, x), max(self.press_x, x))
+            pair = self._span_pair(span[0], span[1], color=self.ROI_COLOR, alpha=0.5, zorder=10)
+            for patch in pair:
+                patch.event_data = span
+            self.burst_patches.append(pair)
+            self.last_detected_events.append(span)
+        self.is_adding = self.press_x = None
         self._redraw()
 
     def remove_patch(self, patch_pair):

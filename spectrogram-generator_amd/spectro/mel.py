@@ -82,8 +82,10 @@ class MelBank:
         return np.moveaxis(out, 1, 2)
 
     def stft_mel_ptr(self, plan, x_ptr, n_samples, clip_stride, n_clips, out_ptr, out_clip_stride, log_scale=False, stream=None):
+        if self.n_bins != plan.n_bins:
+            raise ValueError(f"mel bank built for nfft {self.nfft} ({self.n_bins} bins), plan has {plan.n_bins} bins")
         _capi.check(_capi.lib().sg_stft_mel(plan.handle, C.c_void_p(x_ptr), int(n_samples), int(clip_stride), int(n_clips),
-                                            C.c_void_p(self._dev.ptr), self.n_mels, self._k_lo, self._k_hi,
+                                            C.c_void_p(self._dev.ptr), self.n_bins, self.n_mels, self._k_lo, self._k_hi,
                                             int(bool(log_scale)), C.c_void_p(out_ptr), int(out_clip_stride), C.c_void_p(stream)))
 
     def close(self):

@@ -96,20 +96,23 @@ def import_reference_plotengine():
         sys.modules[name] = m
         return m
 
-    qtw, qtc, qtg = mod("PyQt5.QtWidgets"), mod("PyQt5.QtCore"), mod("PyQt5.QtGui", QCursor=object)
+    qtw = mod("PyQt5.QtWidgets", QFileDialog=object)
+    qtc = mod("PyQt5.QtCore", Qt=types.SimpleNamespace(UserRole=256))
+    qtg = mod("PyQt5.QtGui", QCursor=object)
     mod("PyQt5", QtWidgets=qtw, QtCore=qtc, QtGui=qtg)
     mod("matplotlib.backends.backend_qt5agg", FigureCanvasQTAgg=FigureCanvasAgg)
-
-    class _NoHMM:
-        def __init__(self, *a, **k):
-            pass
-    hm = mod("hmmlearn.hmm", GaussianHMM=_NoHMM)
-    mod("hmmlearn", hmm=hm)
+    # hmmlearn is absent here: the deterministic stand-in of tests/hmm_standin.py takes its place on BOTH sides (the reference's
+    # engine below, this repository's engine in the GPU tests), so the logic around the model is what gets compared
+    sys.path.insert(0, os.path.dirname(HERE))
+    import hmm_standin
+    hmm_standin.install(sys.modules)
     sys.path.insert(0, REFERENCE)
     try:
         import PlotEngine as ref_mod          # noqa: N813
+        import ExportManager as ref_export    # noqa: N813
     finally:
         sys.path.remove(REFERENCE)
+    import_reference_plotengine.export_manager = ref_export.ExportManager
     return ref_mod.PlotEngine
 
 
@@ -270,14 +273,112 @@ def g5_edges():
     _save("g5_edges.npz", **out)
 
 
+# ---------------------------------------------------------------------------
+# g6: the reference's CONSUMERS driven against the reference engine: GUI.plot_selected's call sequence
+# (GUI.py:374-453), Auto-Detect / Learn (GUI.py:455-476, 286-312) and ExportManager.export_to_csv
+# (ExportManager.py:13-90).  Stored: engine state the consumers read and the CSV text they write.
+# ---------------------------------------------------------------------------
+class FakeItem:
+    """What GUI.py hands around as tree items: only ``.data(0, Qt.UserRole)`` (the display name) is ever read."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def data(self, column, role):
+        return self.name
+
+
+def consumer_sweeps():
+    """three "sweeps" of one recording + one of another, 500 Hz, eeg-like with bursts at known places"""
+    rng = np.random.default_rng(11)
+    out = []
+    for i, (name, n) in enumerate((("/data/recA_sweep0", 6000), ("/data/recA_sweep1", 5000), ("/data/recB_sweep3", 7000))):
+        t = np.arange(n) / 500.0
+        x = 0.2 * rng.standard_normal(n) + 1.0
+        for b0 in (2.0 + i, 7.0 + 0.5 * i):
+            x += np.where((t > b0) & (t < b0 + 1.5), 2.0 * np.sin(2 * np.pi * 12 * t), 0.0)
+        out.append((name, x))
+    return out
+
+
+CONSUMER_SETTINGS = {"combine": False, "draw_raw": True, "draw_proc": False, "mode_raw": "Both", "mode_proc": "None",
+                     "nperseg": 256, "fmin": 5.0, "fmax": 30.0, "log_scale": False}
+
+
+def g6_consumers(PlotEngine):
+    import tempfile
+    ExportManager = import_reference_plotengine.export_manager
+    sweeps = consumer_sweeps()
+    out = {"meta": np.array(_meta(source="reference PlotEngine + ExportManager via stand-in import; HMM = tests/hmm_standin.py",
+                                  sweeps_sha=sha(np.concatenate([x for _, x in sweeps]))))}
+
+    def export(eng):
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "bursts.csv")
+            msg = ExportManager().export_to_csv(path, eng)
+            text = open(path).read() if os.path.exists(path) else ""
+        return np.array(msg), np.array(text)
+
+    for tag, combine in (("single", False), ("combined", True)):
+        eng = PlotEngine()
+        settings = dict(CONSUMER_SETTINGS, combine=combine)
+        infos = [{"item": FakeItem(n), "signal_raw": x, "signal_proc": None, "fs": 500.0} for n, x in (sweeps if combine else sweeps[:1])]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            eng.plot_sweeps(infos, settings)                       # GUI.py:437
+            eng.draw()                                             # GUI.py:448
+        out[f"{tag}__abs_power"] = np.float64(eng.calculate_absolute_power())     # GUI.py:451
+        out[f"{tag}__last_t"] = np.asarray(eng.last_t)
+        out[f"{tag}__last_f"] = np.asarray(eng.last_f)
+        out[f"{tag}__segments"] = np.array([[s["start_time_combined"], s["end_time_combined"]] for s in eng.segment_map]).reshape(-1, 2)
+        out[f"{tag}__segment_names"] = np.array([s["source_item"].name for s in eng.segment_map] or [""])
+        out[f"{tag}__last_raw_t_end"] = np.float64(eng.last_raw_t[-1]) if len(eng.last_raw_t) else np.float64(-1)
+        out[f"{tag}__combined_raw_len"] = np.int64(-1 if eng.combined_raw is None else len(eng.combined_raw))
+        msg0, _ = export(eng)                                      # nothing detected yet
+        out[f"{tag}__export_empty_msg"] = msg0
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ev = eng.unsupervised_detect()                         # GUI.py:464
+        out[f"{tag}__auto_events"] = np.array(ev, dtype=np.float64).reshape(-1, 2)
+        out[f"{tag}__auto_transmat"] = np.asarray(eng.model.transmat_)
+        eng.plot_detection_lines(ev)                               # GUI.py:471
+        out[f"{tag}__auto_n_patches"] = np.int64(len(eng.burst_patches))
+        msg, text = export(eng)                                    # GUI.py:496-527 -> ExportManager.py:13
+        out[f"{tag}__auto_csv_msg"], out[f"{tag}__auto_csv"] = msg, text
+        # Learn: two hand-drawn regions around known bursts (GUI.py:286-312); plot_detection_lines stands in for the mouse
+        rois = [(1.6, 4.0), (6.6, 9.0)] if not combine else [(1.6, 4.0), (14.6, 17.2), (24.5, 27.0)]
+        eng.plot_detection_lines(rois)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ev2 = eng.learn_and_detect()                           # GUI.py:300
+        out[f"{tag}__learn_rois"] = np.array(rois)
+        out[f"{tag}__learn_events"] = np.array(ev2, dtype=np.float64).reshape(-1, 2)
+        out[f"{tag}__learn_transmat"] = np.asarray(eng.model.transmat_)
+        out[f"{tag}__learn_means"] = np.asarray(eng.model.means_)
+        eng.plot_detection_lines(ev2)                              # GUI.py:307
+        msg, text = export(eng)
+        out[f"{tag}__learn_csv_msg"], out[f"{tag}__learn_csv"] = msg, text
+        # refined model: Auto-Detect now skips the fit (PlotEngine.py:417) and decodes with the supervised parameters
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ev3 = eng.unsupervised_detect()
+        out[f"{tag}__refined_events"] = np.array(ev3, dtype=np.float64).reshape(-1, 2)
+    _save("g6_consumers.npz", **out)
+
+
 def main():
     os.makedirs(HERE, exist_ok=True)
+    if "--only-consumers" in sys.argv:
+        g6_consumers(import_reference_plotengine())
+        return
     g2_cfg1_extended()
     g3_cfg2_sampled()
     g4_sweep()
     g5_edges()
     if "--no-reference" not in sys.argv:
-        g1_reference_engine(import_reference_plotengine())
+        engine = import_reference_plotengine()
+        g1_reference_engine(engine)
+        g6_consumers(engine)
 
 
 if __name__ == "__main__":

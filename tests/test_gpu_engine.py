@@ -223,10 +223,14 @@ def test_streaming_many_small_chunks(nperseg, hop, max_chunk):
     st.close()
 
 
+@pytest.mark.parametrize("variant", ["default", "ws", "ws_cons4"])
 @pytest.mark.parametrize("hop,n_mels,detrend", [(256, 80, "constant"), (896, 40, "constant"), (130, 128, False)])
-def test_fused_stft_mel(hop, n_mels, detrend):
+def test_fused_stft_mel(hop, n_mels, detrend, variant, monkeypatch):
     """cfg3 fused kernel (sg_stft_mel): equals mel(oracle PSD) and the unfused sg_stft + sg_mel path, incl. a frame
-    count that is not a multiple of the 16-frame tile and several clips."""
+    count that is not a multiple of the 16-frame tile and several clips; every kernel form the library carries."""
+    for k, v in {"default": {}, "ws": {"SPECTRO_FUSED_WS": "1"},
+                 "ws_cons4": {"SPECTRO_FUSED_WS": "1", "SPECTRO_FUSED_CONS": "4"}}[variant].items():
+        monkeypatch.setenv(k, v)
     from oracle import mel_oracle
     from spectro import _capi, engine
     from spectro.mel import MelBank

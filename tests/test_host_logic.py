@@ -26,7 +26,7 @@ def test_abi_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in spectro.h but not exported"
     assert declared == set(_capi.SIGNATURES), declared ^ set(_capi.SIGNATURES)
-    assert lib.sg_version() == 100
+    assert lib.sg_version() == 101
 
 
 def test_abi_host_side_helpers_without_gpu():
@@ -346,6 +346,51 @@ def test_mel_weights_host_function_matches_own_oracle():
             blk = w[:, 16 * t:16 * t + 16]
             nz = np.nonzero(blk.any(axis=1))[0]
             assert klo[t] <= nz[0] and khi[t] >= nz[-1] + 1 and klo[t] % 4 == 0 and khi[t] % 4 == 0
+
+
+def test_mel_weights_pinned_to_the_published_htk_definition():
+    """X1: the mel bank against the PUBLISHED definition, not against this repository's own restatement: HTK mel scale
+    m = 2595 log10(1 + f/700) (Young et al., HTK Book, eq. 5.13), n_mels + 2 band edges equally spaced in mel between
+    fmin and fmax, triangular filters of unit peak evaluated at the rfft bin frequencies (what
+    torchaudio.functional.melscale_fbanks(norm=None, mel_scale="htk") and librosa.filters.mel(htk=True, norm=None)
+    compute).  Hand-derived vectors (pocket-calculator arithmetic from the closed form, cfg3's bank: nfft 1024, 48 kHz,
+    80 bands, 0..24 kHz) plus the closed form evaluated independently here."""
+    import ctypes as C
+    import math
+    from spectro import _capi
+    nfft, fs, nm, lo, hi = 1024, 48000.0, 80, 0.0, 24000.0
+    w = np.empty((nfft // 2 + 1, nm))
+    _capi.check(_capi.lib().sg_mel_weights(nfft, fs, nm, lo, hi, w.ctypes.data_as(C.POINTER(C.c_double))))
+    # mel(24 kHz) = 2595 log10(1 + 24000/700) = 2595 * 1.5475989... = 4016.0192; 81 equal steps of 49.58048 mel;
+    # edge j sits at 700 (10^(j * 49.58048 / 2595) - 1) Hz:
+    edges = {1: 31.48293609949191, 40: 3367.657865996134, 41: 3550.603312667209, 80: 22936.91502114318, 81: 24000.0}
+    mel_hi = 2595.0 * math.log10(1.0 + 24000.0 / 700.0)
+    assert abs(mel_hi - 4016.019179871836) < 1e-9
+    for j, f_hz in edges.items():
+        assert abs(700.0 * (10.0 ** (j * mel_hi / 81.0 / 2595.0) - 1.0) - f_hz) < 1e-8
+    # band b spans edges b, b+1 (peak), b+2; bin k is at k * 46.875 Hz.  (bin, band) -> weight:
+    #   bin 72 = 3375.000 Hz on the falling side of band 39: (3550.6033 - 3375) / (3550.6033 - 3367.6579) = 0.95986709
+    #   bin 75 = 3515.625 Hz on the rising side of band 40:  (3515.625 - 3367.6579) / (3550.6033 - 3367.6579) = 0.80880468
+    #   bin 500 = 23437.5 Hz, falling side of the last band: (24000 - 23437.5) / (24000 - 22936.9150) = 0.52912045
+    #   bin 1 = 46.875 Hz, falling side of band 0:           (64.3818369 - 46.875) / (64.3818369 - 31.4829361) = 0.53214048
+    #   bin 9 = 421.875 Hz, rising side of band 10:          (421.875 - 386.8250360) / (435.7056691 - 386.8250360) = 0.71705217
+    #   bin 221 lies outside band 60 (9105.45 .. 10007.30 Hz): 0
+    hand = {(72, 39): 0.9598670853116857, (75, 40): 0.808804683015161, (500, 79): 0.5291204477415157, (1, 0): 0.5321404805975217,
+            (9, 10): 0.7170521687589072, (221, 60): 0.0}
+    for (k, b), v in hand.items():
+        assert abs(w[k, b] - v) < 1e-12, (k, b, w[k, b], v)
+    # the closed form over the whole bank, written out independently of oracle/mel_oracle.py (scalar loops)
+    for nfft2, fs2, nm2, lo2, hi2 in [(1024, 48000.0, 80, 0.0, 24000.0), (512, 16000.0, 40, 50.0, 7600.0)]:
+        w2 = np.empty((nfft2 // 2 + 1, nm2))
+        _capi.check(_capi.lib().sg_mel_weights(nfft2, fs2, nm2, lo2, hi2, w2.ctypes.data_as(C.POINTER(C.c_double))))
+        m_lo, m_hi = 2595.0 * math.log10(1.0 + lo2 / 700.0), 2595.0 * math.log10(1.0 + hi2 / 700.0)
+        e = [700.0 * (10.0 ** ((m_lo + (m_hi - m_lo) * j / (nm2 + 1)) / 2595.0) - 1.0) for j in range(nm2 + 2)]
+        for b in range(nm2):
+            for k in range(nfft2 // 2 + 1):
+                f = k * fs2 / nfft2
+                ref = max(0.0, min((f - e[b]) / (e[b + 1] - e[b]), (e[b + 2] - f) / (e[b + 2] - e[b + 1])))
+                assert abs(w2[k, b] - ref) < 1e-11, (k, b)
+        assert abs(w2.max() - 1.0) < 0.2 and w2.min() == 0.0       # unit-peak triangles (no area normalisation)
 
 
 def test_jet_lut_matches_matplotlib():
