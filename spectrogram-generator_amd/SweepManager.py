@@ -135,10 +135,16 @@ class SweepManager:
             raise ValueError("batch calls need clips of one length and one sampling rate")
         return np.stack([np.asarray(s) for s in sigs]), rates[0]
 
-    def spectrogram_batch(self, names, nperseg, processed=False, **kw):
-        """One device launch over all named clips; returns ``(f, t, Sxx[clip, freq, time])``."""
-        from spectro import spectrogram
+    def spectrogram_batch(self, names, nperseg, processed=False, pipeline=False, **kw):
+        """All named clips through the device; returns ``(f, t, Sxx[clip, freq, time])``.
+
+        ``pipeline=True``: chunked, double-buffered transfers into pinned host memory (``spectro.pipeline``): the upload of
+        one chunk overlaps the download of the previous one, int16 PCM travels as int16; same values bit for bit."""
         x, fs = self._stack(names, processed)
+        if pipeline:
+            from spectro.pipeline import stft_pipelined
+            return stft_pipelined(x, fs=fs, nperseg=nperseg, **kw)
+        from spectro import spectrogram
         return spectrogram(x, fs=fs, nperseg=nperseg, **kw)
 
     def parameter_sweep(self, names, n_ffts, hops, processed=False, window="hann", reduce=None):

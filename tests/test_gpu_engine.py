@@ -294,6 +294,56 @@ def test_sharded_sweep_single_rank_on_device():
         m = (f >= 200.0) & (f <= 8000.0)
         ref = np.log10(s[m].sum(axis=0) + 1e-20)
         assert v.shape == ref.shape and np.allclose(v, ref, atol=2e-5), (clip, n, h)
+    # the batched deal (one upload, one call per pair) and the per-item deal give the same numbers
+    per_item = sweep.sharded_sweep(clips, 48000.0, [256, 1024, 4096], [64, 256], fmin=200.0, fmax=8000.0, batched=False)
+    for k, v in per_item.items():
+        assert np.array_equal(v, res[k]), k
+
+
+def test_device_clips_products_vs_oracle():
+    """DeviceClips: clips uploaded once; band features (whole batch and a clip range), log display through the fused kernel
+    (nperseg 1024) and through the composed path (nperseg 512), int16 clips."""
+    from spectro import engine
+    rng = np.random.default_rng(33)
+    x = (rng.standard_normal((5, 20000)) * 0.2).astype(np.float32)
+    dc = engine.DeviceClips(x)
+    try:
+        for n, h in ((1024, 256), (512, 128), (1000, 250)):
+            t, feats = dc.band_log_power(16000.0, n, h, 100.0, 3000.0, window="hann")
+            for c in range(5):
+                fo, to, so = orc.spectrogram(x[c], fs=16000.0, nperseg=n, window="hann", noverlap=n - h)
+                m = (fo >= 100.0) & (fo <= 3000.0)
+                lp = np.log10(so[m].sum(axis=0) + 1e-20)
+                np.testing.assert_array_equal(t, to)
+                assert np.allclose(feats[c, :, 0], lp, atol=2e-5)
+                assert np.allclose(feats[c, :, 1], np.diff(lp, prepend=lp[0]), atol=4e-5)
+            t2, part = dc.band_log_power(16000.0, n, h, 100.0, 3000.0, window="hann", clip_range=(1, 4))
+            assert np.array_equal(part, feats[1:4])
+        for n, h in ((1024, 256), (512, 128)):
+            fo, to, so = orc.spectrogram(x, fs=16000.0, nperseg=n, window="hann", noverlap=n - h)
+            gmax = float(so.max()) * 1e8                       # well-conditioned display minimum (tests/test_gpu_db.py)
+            fb, tt, img = dc.log_image(16000.0, n, h, 100.0, 3000.0, gmax, window="hann")
+            m = (fo >= 100.0) & (fo <= 3000.0)
+            band = so[:, m, :]
+            db = 10.0 * np.log10(np.clip(band / (np.float32(gmax) + np.float32(1e-20)), 0, 1) + np.float32(1e-12))
+            ref = (db - db.min()) / (db.max() - db.min())      # min-max over the WHOLE batch (one global_max, one image)
+            np.testing.assert_array_equal(fb, fo[m])
+            assert img.shape == ref.shape and np.abs(img - ref).max() <= 2e-3
+            strong = band >= 1e-3 * so.max(axis=1, keepdims=True)
+            assert np.abs(img[strong] - ref[strong]).max() <= 1e-4
+    finally:
+        dc.free()
+    xi = (x * 20000).astype(np.int16)
+    di = engine.DeviceClips(xi)
+    try:
+        dev = di.stft(fs=16000.0, window="hann", nperseg=1024, hop=256)
+        fo, to, so = orc.spectrogram(xi, fs=16000.0, nperseg=1024, window="hann", noverlap=768)
+        assert_spec_close(dev.to_host(), so, time_axis=-1)
+        dev.free()
+        t, feats = di.band_log_power(16000.0, 1024, 256, 0.0, 8000.0, window="hann")
+        assert np.allclose(feats[..., 0], np.log10(so.sum(axis=1) + 1e-20), atol=2e-5)
+    finally:
+        di.free()
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
@@ -402,3 +452,50 @@ def test_plotengine_fast_image_equals_pcolormesh_colours(dtype):
     assert np.allclose(ext, (t[0] - (t[1] - t[0]) / 2, t[-1] + (t[1] - t[0]) / 2, f[0] - (f[1] - f[0]) / 2, f[-1] + (f[1] - f[0]) / 2))
     assert fast.ax_spec.get_xlim() == slow.ax_spec.get_xlim() and fast.ax_spec.get_ylim() == slow.ax_spec.get_ylim()
     print(f"plot_extra: pcolormesh {t_slow*1e3:.1f} ms, imshow {t_fast*1e3:.1f} ms")
+
+
+@pytest.mark.parametrize("dtype,mode", [(np.float32, "psd"), (np.int16, "psd"), (np.float64, "psd"), (np.float32, "complex")])
+def test_pipelined_ingest_equals_unpipelined_and_oracle(dtype, mode):
+    """N2: chunked double-buffered transfers into pinned memory give the unpipelined result bit for bit (several chunk
+    sizes incl. a ragged last chunk and the single-chunk case) and match the oracle on sampled frames."""
+    import spectro
+    from spectro.pipeline import stft_pipelined, pinned_pool_clear
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((7, 30000)) * 0.3
+    x = (x * 8000).astype(np.int16) if dtype == np.int16 else x.astype(dtype)
+    kw = dict(fs=16000.0, nperseg=1024 if dtype != np.float64 else 512, window="hann", noverlap=768 if dtype != np.float64 else 384, mode=mode)
+    f0, t0, s0 = spectro.spectrogram(x, **kw)
+    for chunk in (2 * x[0].nbytes, 3 * x[0].nbytes + 5, 1 << 30, 1):
+        f1, t1, s1 = stft_pipelined(x, chunk_bytes=chunk, **kw)
+        np.testing.assert_array_equal(f1, f0)
+        np.testing.assert_array_equal(t1, t0)
+        assert s1.dtype == s0.dtype and s1.shape == s0.shape
+        np.testing.assert_array_equal(s1, s0)
+    fo, to, so = orc.spectrogram(x, **kw)
+    assert_spec_close(s1, so, time_axis=-1) if dtype != np.float64 else np.testing.assert_allclose(s1, so, rtol=0, atol=1e-11 * so.max())
+    # the result is an ordinary numpy array that outlives the call and can be written to
+    keep = s1.copy()
+    del s1, f1, t1
+    stft_pipelined(x, **kw)
+    np.testing.assert_array_equal(keep, s0)
+    pinned_pool_clear()
+    from spectro.pipeline import workspace_release
+    workspace_release()
+
+
+def test_sweepmanager_batch_pipeline_flag():
+    from SweepManager import SweepManager
+    sm = SweepManager()
+    rng = np.random.default_rng(2)
+    for i in range(5):
+        sm.add_signal(f"rec_sweep{i}", (rng.standard_normal(20000) * 0.1).astype(np.float32), 8000.0)
+    names = list(sm.data)
+    a = sm.spectrogram_batch(names, 256, window="hann", noverlap=192)
+    b = sm.spectrogram_batch(names, 256, window="hann", noverlap=192, pipeline=True)
+    for u, v in zip(a, b):
+        np.testing.assert_array_equal(u, v)
+    sweep = sm.parameter_sweep(names, [256, 1024], [64, 256])
+    for (n, h), (f, t, s) in sweep.items():
+        fo, to, so = orc.spectrogram(np.stack([sm.data[k]["raw"] for k in names]), fs=8000.0, nperseg=n, window="hann", noverlap=n - h)
+        np.testing.assert_array_equal(t, to)
+        assert_spec_close(s, so, time_axis=-1)
