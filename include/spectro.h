@@ -102,8 +102,10 @@ int sg_stream_sync(void* stream); /* blocks the caller */
  *            for the reference call); cast to `dtype` like scipy:2083-2084
  *   fs       sampling rate; scale = 1/(fs*sum(w^2)) or 1/sum(w)^2 (scipy:2086-2089),
  *            computed in `dtype` precision like scipy does
- * Supported on the device: every nfft >= 2 (powers of two by the Stockham kernels,
- * everything else by Bluestein on top of them); SG_F64 up to nfft = 8192 (pow2) .
+ * Supported on the device: every nfft from 2 to 2^20 in SG_F32 and SG_F64 -- register kernels for f32 nfft 256..4096, an LDS
+ * Stockham kernel for the other powers of two up to 16384 (f32) / 8192 (f64), chirp-z (Bluestein) for everything else, in
+ * LDS while the convolution buffer fits and in a stream-ordered HBM workspace above that (e.g. f64 nperseg 4097..8191,
+ * which the reference GUI's spin box reaches).
  */
 int sg_plan_create(sg_plan** plan, int nperseg, int nfft, int hop, const double* window,
                    int detrend, double fs, int scaling, int mode, int dtype);

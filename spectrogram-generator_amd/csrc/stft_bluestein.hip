@@ -9,6 +9,12 @@
 //     -> inverse DIT (bit-reversed in, natural out).  No bit-reversal pass, a single L-point complex buffer.
 // One 256-thread workgroup owns one frame at a time.  Framing / detrend / window / epilogue are the same
 // code path as the Stockham kernel (scipy/signal/_spectral_py.py:2180-2202, :2125-2134).
+// The L-point buffer lives in LDS while it fits (f32: nfft <= 8192, f64: nfft <= 4096); larger transforms -- f64 signals
+// with a non-power-of-two nperseg above 4096, which the GUI's 32..8192 spin box and scipy's nperseg := len(x) clamp both
+// reach, and every power of two beyond the Stockham kernel -- run the same butterflies on a per-workgroup slice of a
+// stream-ordered HBM workspace (hipMallocAsync / hipFreeAsync around the launch, so a plan stays re-entrant per stream);
+// that slice is L2-resident (<= 1 MiB per workgroup at the largest GUI size) and the path is a correctness net for
+// GUI-sized calls, not a throughput kernel.
 #include "spectro_internal.h"
 
 #include <cmath>
@@ -40,13 +46,16 @@ struct BsParams {
     const Cx<T>* filt;       // [L]      FFT_L(h)/L in bit-reversed order
     const Cx<T>* tw;         // [L/2]    exp(-2*pi*i*k/L)
     T scale;
+    Cx<T>* work;             // GLOBAL: [gridDim.x][L] convolution buffers in HBM
 };
 
-template <typename T>
+// GLOBAL: the buffer is this workgroup's slice of p.work (visible to the workgroup's waves across __syncthreads():
+// they share the CU's write-through L1), only the reduction scratch is in LDS.
+template <typename T, bool GLOBAL>
 __global__ __launch_bounds__(kThreads) void stft_bluestein_kernel(const BsParams<T> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    Cx<T>* const C = reinterpret_cast<Cx<T>*>(smem_raw);
-    double* const red = reinterpret_cast<double*>(C + p.L);
+    Cx<T>* const C = GLOBAL ? p.work + static_cast<size_t>(blockIdx.x) * p.L : reinterpret_cast<Cx<T>*>(smem_raw);
+    double* const red = GLOBAL ? reinterpret_cast<double*>(smem_raw) : reinterpret_cast<double*>(reinterpret_cast<Cx<T>*>(smem_raw) + p.L);
     const int tid = threadIdx.x;
     const int n = p.nperseg, L = p.L, halfL = L >> 1;
     const int nbins = p.nfft / 2 + 1;
@@ -177,14 +186,31 @@ int launch_t(const sg_plan& p, const StftArgs& a) {
     prm.filt = static_cast<const Cx<T>*>(p.bs_filter_dev);
     prm.tw = static_cast<const Cx<T>*>(p.bs_tw_dev);
     prm.scale = static_cast<T>(p.mode == SG_MODE_PSD ? p.scale : std::sqrt(p.scale));
-    const size_t lds = static_cast<size_t>(p.bs_len) * 2 * sizeof(T) + 2 * kThreads * sizeof(double);
-    auto kern = stft_bluestein_kernel<T>;
-    if (lds > 64 * 1024)
-        SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    const size_t red_bytes = 2 * kThreads * sizeof(double);
+    const size_t lds = static_cast<size_t>(p.bs_len) * 2 * sizeof(T) + red_bytes;
     int64_t n_wg = prm.total_frames;
-    const int64_t cap = static_cast<int64_t>(p.n_cu) * 8;
-    if (n_wg > cap) n_wg = cap;
-    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(n_wg)), dim3(kThreads), lds, a.stream, prm);
+    if (lds <= 160 * 1024) {
+        auto kern = stft_bluestein_kernel<T, false>;
+        if (lds > 64 * 1024)
+            SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        const int64_t cap = static_cast<int64_t>(p.n_cu) * 8;
+        if (n_wg > cap) n_wg = cap;
+        hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(n_wg)), dim3(kThreads), lds, a.stream, prm);
+    } else {
+        // oversized: one L-point buffer per workgroup in a stream-ordered HBM workspace
+        const int64_t cap = static_cast<int64_t>(p.n_cu);
+        if (n_wg > cap) n_wg = cap;
+        const size_t bytes = static_cast<size_t>(n_wg) * p.bs_len * 2 * sizeof(T);
+        void* work = nullptr;
+        SG_HIP(hipMallocAsync(&work, bytes, a.stream));
+        prm.work = static_cast<Cx<T>*>(work);
+        hipLaunchKernelGGL((stft_bluestein_kernel<T, true>), dim3(static_cast<unsigned>(n_wg)), dim3(kThreads), red_bytes, a.stream, prm);
+        const hipError_t le = hipGetLastError();
+        const hipError_t fe = hipFreeAsync(work, a.stream);
+        if (le != hipSuccess) return hip_fail(le, "stft_bluestein (HBM workspace) launch");
+        if (fe != hipSuccess) return hip_fail(fe, "hipFreeAsync");
+        return SG_OK;
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "stft_bluestein launch");
     return SG_OK;
@@ -263,11 +289,8 @@ int build_tables_t(sg_plan& p) {
 int build_bluestein_tables(sg_plan& p) {
     int L = 1;
     while (L < 2 * p.nfft - 1) L <<= 1;
-    const size_t esz = p.dtype == SG_F64 ? 8 : 4;
-    const size_t lds = static_cast<size_t>(L) * 2 * esz + 2 * kThreads * sizeof(double);
-    if (lds > 160 * 1024) {
-        set_error("nfft=%d (%s) needs a %d-point chirp-z convolution = %zu B of LDS (> 160 KiB)", p.nfft,
-                  p.dtype == SG_F64 ? "f64" : "f32", L, lds);
+    if (p.nfft > (1 << 20)) {        // tables of 2^22 complex entries and a 64 MiB buffer per workgroup are where this stops
+        set_error("nfft=%d is beyond the chirp-z path (nfft <= 1048576)", p.nfft);
         return SG_ERR_UNSUPPORTED;
     }
     p.bs_len = L;

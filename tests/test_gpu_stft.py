@@ -222,6 +222,37 @@ def test_edges_golden(sp, tag):
         _check(s, ref, ref.dtype)
 
 
+@pytest.mark.parametrize("nperseg,dtype", [(4100, np.float64), (6000, np.float64), (8191, np.float64), (8192, np.float64),
+                                           (16384, np.float64), (12000, np.float32), (8190, np.float32)])
+def test_gui_range_large_nperseg(sp, nperseg, dtype):
+    """The GUI's nperseg spin box goes to 8192 (GUI.py:87-89) and neo / H5 signals are float64: non-power-of-two f64 sizes
+    above 4096 need a 16384-point chirp-z convolution (256 KiB) that no longer fits the LDS and runs in the HBM workspace;
+    so do powers of two beyond the Stockham kernel.  Reference call (Tukey, hop = n - n//8) on an ephys-like trace."""
+    rng = np.random.default_rng(nperseg)
+    n_samples = 3 * nperseg + 777
+    x = (np.cumsum(rng.standard_normal(n_samples)) * 0.01 + 0.2 * rng.standard_normal(n_samples) + 3.0).astype(dtype)
+    f, t, s = sp.spectrogram(x, fs=1000.0, nperseg=nperseg, scaling="density", mode="psd")
+    fo, to, so = orc.spectrogram(x, fs=1000.0, nperseg=nperseg, scaling="density", mode="psd")
+    np.testing.assert_array_equal(f, fo)
+    np.testing.assert_array_equal(t, to)
+    assert s.shape == so.shape == (nperseg // 2 + 1, 3) and s.dtype == so.dtype
+    if dtype == np.float64:
+        assert np.abs(s - so).max() <= 1e-11 * np.abs(so).max()
+    else:
+        assert_spec_close(s, so, time_axis=-1)
+    # and the two paths of the engine that sit on it
+    from PlotEngine import PlotEngine
+    eng = PlotEngine()
+    settings = {"nperseg": nperseg, "fmin": 0.0, "fmax": 30.0, "log_scale": True, "mode_raw": "Spectrogram", "mode_proc": "None",
+                "draw_raw": False, "draw_proc": False}
+    eng.plot_extra(x, None, 1000.0, settings)
+    m = (fo >= 0.0) & (fo <= 30.0)
+    assert eng.last_Sxx.shape == so[m].shape
+    tf, feats = eng._calculate_features(x, 1000.0, settings)
+    lp = np.log10(so[m].sum(axis=0) + 1e-20)
+    assert np.allclose(feats[:, 0], lp, atol=1e-9 if dtype == np.float64 else 2e-5)
+
+
 def test_axis_argument(sp):
     rng = np.random.default_rng(8)
     x = rng.standard_normal((700, 3)).astype(np.float32)
