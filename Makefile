@@ -5,7 +5,7 @@ CC      ?= gcc
 PKG     := spectrogram-generator_amd
 CSRC    := $(PKG)/csrc
 LIBDIR  := $(PKG)/lib
-SOURCES := spectro_api stft_r8x3 stft_rsmall stft_rbig stft_stockham stft_bluestein epilogue mel stft_mel_fused
+SOURCES := host_shim spectro_api stft_r8x3 stft_rsmall stft_rbig stft_stockham stft_bluestein epilogue mel stft_mel_fused
 OBJS    := $(SOURCES:%=$(LIBDIR)/%.o)
 HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -fno-gpu-rdc -Wall -Wno-unused-function -Wno-unused-result
 # register-FFT kernels: gfx950 issues v_pk_*_f32 at half rate, so no SLP packing (see build.py)
@@ -17,6 +17,19 @@ $(LIBDIR)/%.o: $(CSRC)/%.hip $(CSRC)/fft_wave.h $(CSRC)/spectro_internal.h inclu
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) $(if $(filter $*,$(NOSLP)),-fno-slp-vectorize) -I include -I $(CSRC) -c $< -o $@
 
+$(LIBDIR)/host_shim.o: $(CSRC)/host_shim.cpp $(CSRC)/host_shim.h include/spectro.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) -x c++ -O3 -std=c++17 -fPIC -Wall -I include -I $(CSRC) -c $< -o $@
+
+# host side of the ABI under the CPU sanitizers (GPU sanitizers are not available on the pool)
+$(LIBDIR)/host_shim_asan: tests/asan_driver.cpp $(CSRC)/host_shim.cpp $(CSRC)/host_shim.h include/spectro.h
+	@mkdir -p $(LIBDIR)
+	g++ -std=c++17 -O1 -g -fno-omit-frame-pointer -fsanitize=address,undefined -fno-sanitize-recover=all -Wall -Wextra -Werror \
+	    -I include -I $(CSRC) tests/asan_driver.cpp $(CSRC)/host_shim.cpp -o $@
+
+asan: $(LIBDIR)/host_shim_asan
+	$(LIBDIR)/host_shim_asan
+
 $(LIBDIR)/libspectro.so: $(OBJS)
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(OBJS) -o $@
 
@@ -26,4 +39,4 @@ examples/c_client: examples/c_client.c include/spectro.h $(LIBDIR)/libspectro.so
 clean:
 	rm -f $(LIBDIR)/*.o $(LIBDIR)/libspectro.so examples/c_client
 
-.PHONY: all clean
+.PHONY: all clean asan

@@ -250,7 +250,9 @@ def spectrogram(x, fs=1.0, window=("tukey", 0.25), nperseg=None, noverlap=None,
     elif mode in ("angle", "phase"):
         res = np.angle(res)
         if mode == "phase":
-            res = np.unwrap(res, axis=-2)
+            # scipy:990-992 unwraps along the FREQUENCY axis of its [..., freq, time] result; here the data is still
+            # frame-major [..., time, freq], so that axis is the last one
+            res = np.unwrap(res, axis=-1)
     res = np.moveaxis(res, -1, -2)                                   # [..., freq, time]
     return f, t, res
 

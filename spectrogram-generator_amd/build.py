@@ -18,7 +18,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libspectro.so")
-SOURCES = ["spectro_api.hip", "stft_r8x3.hip", "stft_rsmall.hip", "stft_rbig.hip", "stft_stockham.hip", "stft_bluestein.hip", "epilogue.hip", "mel.hip", "stft_mel_fused.hip"]
+SOURCES = ["host_shim.cpp", "spectro_api.hip", "stft_r8x3.hip", "stft_rsmall.hip", "stft_rbig.hip", "stft_stockham.hip", "stft_bluestein.hip", "epilogue.hip", "mel.hip", "stft_mel_fused.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-fno-gpu-rdc",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 # Per-file extras.  stft_r8x3 is VALU-bound: gfx950 issues v_pk_*_f32 at half the rate of the plain ops
@@ -38,7 +38,7 @@ def hipcc():
 
 def _deps():
     out = [os.path.join(CSRC, s) for s in SOURCES]
-    out += [os.path.join(CSRC, "fft_wave.h"), os.path.join(CSRC, "spectro_internal.h"), os.path.join(ROOT, "include", "spectro.h"), __file__]
+    out += [os.path.join(CSRC, "fft_wave.h"), os.path.join(CSRC, "spectro_internal.h"), os.path.join(CSRC, "host_shim.h"), os.path.join(ROOT, "include", "spectro.h"), __file__]
     return out
 
 
@@ -57,8 +57,9 @@ def build(force=False, verbose=False):
     t0 = time.time()
     procs = []
     for s in SOURCES:
-        obj = os.path.join(LIBDIR, s.replace(".hip", ".o"))
-        cmd = [hipcc(), *FLAGS, *EXTRA.get(s, []), "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", os.path.join(CSRC, s), "-o", obj]
+        obj = os.path.join(LIBDIR, s.replace(".hip", ".o").replace(".cpp", ".o"))
+        flags = [f for f in FLAGS if not f.startswith(("--offload-arch", "-fno-gpu-rdc"))] + ["-x", "c++"] if s.endswith(".cpp") else FLAGS
+        cmd = [hipcc(), *flags, *EXTRA.get(s, []), "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", os.path.join(CSRC, s), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -99,6 +100,27 @@ def build_c_client(force=False):
         print(r.stdout)
         raise RuntimeError("gcc failed on examples/c_client.c")
     return C_CLIENT
+
+
+SAN_DRIVER_SRC = os.path.join(ROOT, "tests", "asan_driver.cpp")
+SAN_DRIVER = os.path.join(LIBDIR, "host_shim_asan")
+
+
+def build_sanitizer_driver(force=False):
+    """tests/asan_driver.cpp + csrc/host_shim.cpp under g++ -fsanitize=address,undefined (CPU only, no HIP): the host
+    side of the ABI -- argument triage, f / t vectors, mel bank construction, jet table, error strings."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    srcs = [SAN_DRIVER_SRC, os.path.join(CSRC, "host_shim.cpp")]
+    deps = srcs + [os.path.join(CSRC, "host_shim.h"), os.path.join(ROOT, "include", "spectro.h")]
+    if not force and os.path.exists(SAN_DRIVER) and os.path.getmtime(SAN_DRIVER) >= max(os.path.getmtime(d) for d in deps):
+        return SAN_DRIVER
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+           "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), "-I", CSRC, *srcs, "-o", SAN_DRIVER]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        print(r.stdout)
+        raise RuntimeError("g++ -fsanitize failed on the host shim")
+    return SAN_DRIVER
 
 
 if __name__ == "__main__":

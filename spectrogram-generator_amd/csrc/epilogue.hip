@@ -441,35 +441,6 @@ using namespace sg;
 
 extern "C" {
 
-int sg_jet_lut(uint8_t* rgba_host) {
-    if (!rgba_host) { set_error("null pointer"); return SG_ERR_ARG; }
-    // matplotlib _cm.py 'jet' segment data: (x, y) breakpoints, linear in between
-    static const double R[][2] = {{0, 0}, {0.35, 0}, {0.66, 1}, {0.89, 1}, {1, 0.5}};
-    static const double G[][2] = {{0, 0}, {0.125, 0}, {0.375, 1}, {0.64, 1}, {0.91, 0}, {1, 0}};
-    static const double B[][2] = {{0, 0.5}, {0.11, 1}, {0.34, 1}, {0.65, 0}, {1, 0}};
-    // same arithmetic as matplotlib.colors._create_lookup_table (N = 256, gamma = 1): breakpoints scaled by N-1,
-    // sample i at (N-1) * (i * (1/(N-1))), left searchsorted, linear blend; end points taken verbatim
-    auto interp = [](const double (*seg)[2], int n, int i) {
-        if (i == 0) return seg[0][1];
-        if (i == 255) return seg[n - 1][1];
-        const double xind = 255.0 * (static_cast<double>(i) * (1.0 / 255.0));
-        int ind = 0;
-        while (ind < n && seg[ind][0] * 255.0 < xind) ++ind;
-        const double x0 = seg[ind - 1][0] * 255.0, x1 = seg[ind][0] * 255.0;
-        const double distance = (xind - x0) / (x1 - x0);
-        return distance * (seg[ind][1] - seg[ind - 1][1]) + seg[ind - 1][1];
-    };
-    for (int i = 0; i < 256; ++i) {
-        const double c[3] = {interp(R, 5, i), interp(G, 6, i), interp(B, 5, i)};
-        for (int k = 0; k < 3; ++k) {
-            double v = c[k] < 0 ? 0 : (c[k] > 1 ? 1 : c[k]);
-            rgba_host[4 * i + k] = static_cast<uint8_t>(v * 255.0);      // matplotlib bytes=True: (lut * 255).astype(uint8)
-        }
-        rgba_host[4 * i + 3] = 255;
-    }
-    return SG_OK;
-}
-
 int sg_colormap(const float* img_dev, int64_t n, const uint8_t* lut_dev, uint8_t* rgba_dev, void* stream) {
     if (!img_dev || !lut_dev || !rgba_dev || n < 0) { set_error("bad argument"); return SG_ERR_ARG; }
     if (n == 0) return SG_OK;

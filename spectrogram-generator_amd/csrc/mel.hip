@@ -141,54 +141,6 @@ using namespace sg;
 
 extern "C" {
 
-int sg_mel_weights(int nfft, double fs, int n_mels, double fmin, double fmax, double* weights_host) {
-    if (!weights_host || nfft < 2 || n_mels < 1 || !(fs > 0) || !(fmax > fmin) || fmin < 0) {
-        set_error("bad mel filterbank arguments");
-        return SG_ERR_ARG;
-    }
-    const int n_bins = nfft / 2 + 1;
-    auto hz2mel = [](double f) { return 2595.0 * std::log10(1.0 + f / 700.0); };
-    auto mel2hz = [](double m) { return 700.0 * (std::pow(10.0, m / 2595.0) - 1.0); };
-    const double m_lo = hz2mel(fmin), m_hi = hz2mel(fmax);
-    std::vector<double> edges(n_mels + 2);
-    for (int j = 0; j < n_mels + 2; ++j) edges[j] = mel2hz(m_lo + (m_hi - m_lo) * j / (n_mels + 1));
-    for (int k = 0; k < n_bins; ++k) {
-        const double f = static_cast<double>(k) * fs / nfft;
-        for (int m = 0; m < n_mels; ++m) {
-            const double l = edges[m], c = edges[m + 1], r = edges[m + 2];
-            const double up = (f - l) / (c - l), down = (r - f) / (r - c);
-            const double v = up < down ? up : down;
-            weights_host[static_cast<size_t>(k) * n_mels + m] = v > 0.0 ? v : 0.0;
-        }
-    }
-    return SG_OK;
-}
-
-int sg_mel_pack_weights(const double* weights_host, int n_bins, int n_mels, float* packed_host) {
-    if (!weights_host || !packed_host || n_bins < 1 || n_mels < 1) { set_error("bad argument"); return SG_ERR_ARG; }
-    const int k_pad = (n_bins + 15) & ~15, m_pad = ((n_mels + 15) / 16) * 16;
-    for (int m = 0; m < m_pad; ++m)
-        for (int k = 0; k < k_pad; ++k)
-            packed_host[static_cast<size_t>(m) * k_pad + k] =
-                (m < n_mels && k < n_bins) ? static_cast<float>(weights_host[static_cast<size_t>(k) * n_mels + m]) : 0.f;
-    return SG_OK;
-}
-
-int sg_mel_tile_ranges(const double* weights_host, int n_bins, int n_mels, int* k_lo, int* k_hi) {
-    if (!weights_host || !k_lo || !k_hi || n_bins < 1 || n_mels < 1) { set_error("bad argument"); return SG_ERR_ARG; }
-    const int n_tiles = (n_mels + 15) / 16;
-    for (int t = 0; t < n_tiles; ++t) {
-        int lo = n_bins, hi = 0;
-        for (int k = 0; k < n_bins; ++k)
-            for (int m = 16 * t; m < 16 * t + 16 && m < n_mels; ++m)
-                if (weights_host[static_cast<size_t>(k) * n_mels + m] != 0.0) { if (k < lo) lo = k; if (k + 1 > hi) hi = k + 1; }
-        if (hi <= lo) { lo = 0; hi = 0; }
-        k_lo[t] = lo & ~3;
-        k_hi[t] = (hi + 3) & ~3;
-    }
-    return SG_OK;
-}
-
 int sg_mel(const float* spec_dev, int64_t n_frames, int n_bins, const float* weights_dev, int n_mels,
            const int* tile_k_lo, const int* tile_k_hi, int log_scale, float* mel_dev, void* stream) {
     if (!spec_dev || !weights_dev || !mel_dev) { set_error("null pointer"); return SG_ERR_ARG; }

@@ -9,15 +9,6 @@
 
 namespace sg {
 
-static thread_local char g_err[512] = "";
-
-void set_error(const char* fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
-}
-
 int hip_fail(hipError_t e, const char* what) {
     set_error("HIP error %d (%s) in %s", static_cast<int>(e), hipGetErrorString(e), what);
     return SG_ERR_HIP;
@@ -130,10 +121,6 @@ using namespace sg;
 
 extern "C" {
 
-int sg_version(void) { return SG_VERSION; }
-
-const char* sg_last_error(void) { return g_err; }
-
 int sg_device_count(int* count) {
     if (!count) { set_error("null pointer"); return SG_ERR_ARG; }
     int n = 0;
@@ -234,14 +221,7 @@ int sg_plan_create(sg_plan** plan, int nperseg, int nfft, int hop, const double*
                    int scaling, int mode, int dtype) {
     if (!plan || !window) { set_error("null pointer"); return SG_ERR_ARG; }
     *plan = nullptr;
-    if (nperseg < 1) { set_error("nperseg must be a positive integer"); return SG_ERR_ARG; }
-    if (nfft < nperseg) { set_error("nfft must be greater than or equal to nperseg."); return SG_ERR_ARG; }
-    if (hop < 1 || hop > nperseg) { set_error("noverlap must be less than nperseg."); return SG_ERR_ARG; }
-    if (detrend < 0 || detrend > 2) { set_error("Trend type must be 'linear' or 'constant'."); return SG_ERR_ARG; }
-    if (scaling < 0 || scaling > 1) { set_error("Unknown scaling: %d", scaling); return SG_ERR_ARG; }
-    if (mode < 0 || mode > 3) { set_error("unknown value for mode %d", mode); return SG_ERR_ARG; }
-    if (dtype != SG_F32 && dtype != SG_F64) { set_error("bad dtype %d", dtype); return SG_ERR_ARG; }
-    if (!(fs > 0.0) || !std::isfinite(fs)) { set_error("fs must be positive and finite"); return SG_ERR_ARG; }
+    if (int rc = check_plan_args(nperseg, nfft, hop, detrend, fs, scaling, mode, dtype)) return rc;
 
     auto* p = new sg_plan();
     p->nperseg = nperseg; p->nfft = nfft; p->hop = hop;
@@ -346,30 +326,6 @@ int sg_plan_force_kernel(sg_plan* plan, const char* name) {
     }
     set_error("unknown kernel family '%s'", name);
     return SG_ERR_ARG;
-}
-
-// A7 -- must reproduce numpy's arithmetic exactly:
-//   rfftfreq(n, d): val = 1.0/(n*d); results = arange(0, n//2+1) * val         (scipy:2115, d = 1/fs)
-//   time = arange(nperseg/2, N - nperseg/2 + 1, step) / float(fs)              (scipy:2136-2137)
-// numpy's arange(start, stop, step) for doubles fills start + i*step.
-int sg_freqs(int nfft, double fs, double* f_out) {
-    if (!f_out || nfft < 1 || !(fs > 0)) { set_error("bad argument"); return SG_ERR_ARG; }
-    const double d = 1.0 / fs;
-    const double val = 1.0 / (static_cast<double>(nfft) * d);
-    for (int k = 0; k <= nfft / 2; ++k) f_out[k] = static_cast<double>(k) * val;
-    return SG_OK;
-}
-
-int sg_times(int64_t n_samples, int nperseg, int hop, double fs, double* t_out) {
-    if (nperseg < 1 || hop < 1 || !(fs > 0)) { set_error("bad argument"); return SG_ERR_ARG; }
-    if (n_samples < nperseg) return SG_OK;
-    if (!t_out) { set_error("null pointer"); return SG_ERR_ARG; }
-    const int64_t n = (n_samples - nperseg) / hop + 1;
-    const double start = static_cast<double>(nperseg) / 2.0;
-    // numpy arange: first two values are start and start+step, the rest start + i*delta with delta = (start+step)-start
-    const double delta = (start + static_cast<double>(hop)) - start;
-    for (int64_t i = 0; i < n; ++i) t_out[i] = (start + static_cast<double>(i) * delta) / fs;
-    return SG_OK;
 }
 
 int sg_stft(const sg_plan* plan, const void* x_dev, int64_t n_samples, int64_t clip_stride, int n_clips, void* out_dev,

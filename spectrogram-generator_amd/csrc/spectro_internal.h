@@ -6,11 +6,10 @@
 #include <string>
 #include <vector>
 #include "spectro.h"
+#include "host_shim.h"
 
 namespace sg {
 
-// thread-local error plumbing -------------------------------------------------
-void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what);   // records message, returns SG_ERR_HIP
 
 #define SG_HIP(call)                                                   \

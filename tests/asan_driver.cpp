@@ -1,0 +1,102 @@
+// Sanitizer driver for the host side of the C ABI (csrc/host_shim.cpp): built with g++ -fsanitize=address,undefined by
+// spectrogram-generator_amd/build.py:build_sanitizer_driver and run by tests/test_host_logic.py.  Every check prints one line;
+// a failed check or any sanitizer report ends the process with a non-zero status.  TEST INFRASTRUCTURE.
+#include "spectro.h"
+#include "host_shim.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+static int g_checks = 0;
+#define CHECK(cond)                                                                  \
+    do {                                                                             \
+        ++g_checks;                                                                  \
+        if (!(cond)) { std::printf("FAILED line %d: %s\n", __LINE__, #cond); std::exit(1); } \
+    } while (0)
+
+int main() {
+    CHECK(sg_version() == SG_VERSION);
+    // ---- argument triage of sg_plan_create, with scipy's messages ----
+    CHECK(sg::check_plan_args(1024, 1024, 256, 1, 48000.0, 0, 0, SG_F32) == SG_OK);
+    CHECK(sg::check_plan_args(0, 1024, 256, 1, 48000.0, 0, 0, SG_F32) == SG_ERR_ARG && std::strstr(sg_last_error(), "nperseg must be a positive integer"));
+    CHECK(sg::check_plan_args(1024, 512, 256, 1, 48000.0, 0, 0, SG_F32) == SG_ERR_ARG && std::strstr(sg_last_error(), "nfft must be greater than or equal to nperseg."));
+    CHECK(sg::check_plan_args(1024, 1024, 0, 1, 48000.0, 0, 0, SG_F32) == SG_ERR_ARG && std::strstr(sg_last_error(), "noverlap must be less than nperseg."));
+    CHECK(sg::check_plan_args(1024, 1024, 1025, 1, 48000.0, 0, 0, SG_F32) == SG_ERR_ARG);
+    CHECK(sg::check_plan_args(1024, 1024, 256, 3, 48000.0, 0, 0, SG_F32) == SG_ERR_ARG && std::strstr(sg_last_error(), "Trend type"));
+    CHECK(sg::check_plan_args(1024, 1024, 256, 1, 48000.0, 2, 0, SG_F32) == SG_ERR_ARG && std::strstr(sg_last_error(), "Unknown scaling"));
+    CHECK(sg::check_plan_args(1024, 1024, 256, 1, 48000.0, 0, 4, SG_F32) == SG_ERR_ARG);
+    CHECK(sg::check_plan_args(1024, 1024, 256, 1, 48000.0, 0, 0, 7) == SG_ERR_ARG);
+    CHECK(sg::check_plan_args(1024, 1024, 256, 1, 0.0, 0, 0, SG_F32) == SG_ERR_ARG);
+    CHECK(sg::check_plan_args(1024, 1024, 256, 1, NAN, 0, 0, SG_F32) == SG_ERR_ARG);
+    CHECK(sg::check_plan_args(1024, 1024, 256, 1, INFINITY, 0, 0, SG_F32) == SG_ERR_ARG);
+    // a very long message must be truncated, not overflow the thread-local buffer
+    {
+        std::vector<char> big(5000, 'x');
+        big.back() = 0;
+        sg::set_error("%s %s", big.data(), big.data());
+        CHECK(std::strlen(sg_last_error()) < 512);
+    }
+    // ---- A7: f and t vectors ----
+    for (int nfft : {2, 3, 33, 256, 1000, 1024, 8191}) {
+        std::vector<double> f(nfft / 2 + 1);
+        CHECK(sg_freqs(nfft, 48000.0, f.data()) == SG_OK);
+        const double val = 1.0 / (static_cast<double>(nfft) * (1.0 / 48000.0));
+        for (int k = 0; k <= nfft / 2; ++k) CHECK(f[k] == k * val);
+    }
+    CHECK(sg_freqs(0, 1.0, nullptr) == SG_ERR_ARG);
+    CHECK(sg_freqs(16, -1.0, nullptr) == SG_ERR_ARG);
+    {
+        const int64_t cases[][3] = {{480000, 1024, 256}, {16000, 512, 448}, {500, 33, 29}, {256, 256, 224}, {257, 256, 1}, {100, 256, 10}};
+        for (const auto& c : cases) {
+            const int64_t n = c[0] < c[1] ? 0 : (c[0] - c[1]) / c[2] + 1;
+            std::vector<double> t(static_cast<size_t>(n) + 1, -7.0);      // one guard element behind the last frame
+            CHECK(sg_times(c[0], static_cast<int>(c[1]), static_cast<int>(c[2]), 1000.0, n ? t.data() : nullptr) == SG_OK);
+            for (int64_t i = 0; i < n; ++i) CHECK(t[i] == (c[1] / 2.0 + static_cast<double>(i) * c[2]) / 1000.0);
+            CHECK(t[n] == -7.0);
+        }
+        CHECK(sg_times(1000, 0, 10, 1.0, nullptr) == SG_ERR_ARG);
+        CHECK(sg_times(1000, 100, 10, 1.0, nullptr) == SG_ERR_ARG);      // frames exist but no output buffer
+    }
+    // ---- mel bank: exact sizes (no slack behind the buffers), ragged band counts ----
+    const int cfgs[][2] = {{1024, 80}, {512, 40}, {256, 8}, {1024, 128}, {4096, 33}, {2, 1}};
+    for (const auto& c : cfgs) {
+        const int nfft = c[0], nm = c[1], nb = nfft / 2 + 1, nt = (nm + 15) / 16, kpad = (nb + 15) & ~15;
+        std::vector<double> w(static_cast<size_t>(nb) * nm);
+        CHECK(sg_mel_weights(nfft, 48000.0, nm, 0.0, 24000.0, w.data()) == SG_OK);
+        double top = 0;
+        for (double v : w) { CHECK(v >= 0.0 && v <= 1.0 + 1e-12); top = v > top ? v : top; }
+        if (nb > nm + 2) CHECK(top > 0.0);      // (two bins under one triangle sit on its end points)
+        std::vector<int> lo(nt), hi(nt);
+        CHECK(sg_mel_tile_ranges(w.data(), nb, nm, lo.data(), hi.data()) == SG_OK);
+        for (int t = 0; t < nt; ++t) CHECK(lo[t] % 4 == 0 && hi[t] % 4 == 0 && lo[t] <= hi[t] && hi[t] <= ((nb + 3) & ~3));
+        std::vector<float> packed(static_cast<size_t>(16 * nt) * kpad);
+        CHECK(sg_mel_pack_weights(w.data(), nb, nm, packed.data()) == SG_OK);
+        for (int m = 0; m < 16 * nt; ++m)
+            for (int k = 0; k < kpad; ++k) {
+                const float want = (m < nm && k < nb) ? static_cast<float>(w[static_cast<size_t>(k) * nm + m]) : 0.f;
+                CHECK(packed[static_cast<size_t>(m) * kpad + k] == want);
+            }
+    }
+    {
+        std::vector<double> w(513 * 80);
+        CHECK(sg_mel_weights(1024, 48000.0, 80, 100.0, 50.0, w.data()) == SG_ERR_ARG);      // fmax <= fmin
+        CHECK(sg_mel_weights(1024, 48000.0, 0, 0.0, 100.0, w.data()) == SG_ERR_ARG);
+        CHECK(sg_mel_weights(1024, 48000.0, 80, 0.0, 100.0, nullptr) == SG_ERR_ARG);
+        CHECK(sg_mel_pack_weights(nullptr, 513, 80, nullptr) == SG_ERR_ARG);
+        CHECK(sg_mel_tile_ranges(w.data(), 513, 80, nullptr, nullptr) == SG_ERR_ARG);
+    }
+    // ---- jet table ----
+    {
+        std::vector<uint8_t> lut(256 * 4 + 1, 0xAB);
+        CHECK(sg_jet_lut(lut.data()) == SG_OK);
+        CHECK(lut[256 * 4] == 0xAB);
+        CHECK(lut[0] == 0 && lut[1] == 0 && lut[2] == 127 && lut[3] == 255);      // jet(0) = (0, 0, 0.5)
+        CHECK(lut[255 * 4] == 127 && lut[255 * 4 + 1] == 0 && lut[255 * 4 + 2] == 0);  // jet(1) = (0.5, 0, 0)
+        CHECK(sg_jet_lut(nullptr) == SG_ERR_ARG);
+    }
+    std::printf("host shim: %d checks passed under AddressSanitizer + UndefinedBehaviorSanitizer\n", g_checks);
+    return 0;
+}

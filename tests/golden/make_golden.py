@@ -196,6 +196,8 @@ def g2_cfg1_extended():
         "hann256_spectrum": dict(nperseg=512, window="hann", noverlap=256, scaling="spectrum"),
         "hann256_complex": dict(nperseg=512, window="hann", noverlap=256, mode="complex"),
         "hann256_nfft1024": dict(nperseg=512, window="hann", noverlap=256, nfft=1024),
+        "hann256_angle": dict(nperseg=512, window="hann", noverlap=256, mode="angle"),
+        "hann256_phase": dict(nperseg=512, window="hann", noverlap=256, mode="phase"),       # unwrap along frequency (scipy:990-992)
     }.items():
         for dt in (np.float64, np.float32):
             f, t, s = ss.spectrogram(x.astype(dt), fs=16000.0, **{"scaling": "density", "mode": "psd", **kw})

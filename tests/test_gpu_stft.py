@@ -171,10 +171,24 @@ def test_angle_and_phase_modes(sp):
         _, _, so = orc.spectrogram(x, fs=16000.0, nperseg=256, window="hann", noverlap=128, mode=mode)
         _, _, mag = orc.spectrogram(x, fs=16000.0, nperseg=256, window="hann", noverlap=128, mode="magnitude")
         assert s.shape == so.shape
+        strong = mag > 1e-3 * mag.max()
         if mode == "angle":
             d = np.angle(np.exp(1j * (s - so)))
-            strong = mag > 1e-3 * mag.max()
             assert np.abs(d[strong]).max() < 1e-9
+        else:
+            # 'phase' = unwrap(angle) along frequency (scipy:1003): a weak bin whose angle is numerically arbitrary can move
+            # every later bin of that frame by a multiple of 2*pi, so compare modulo 2*pi on strong bins ...
+            d = np.angle(np.exp(1j * (s - so)))
+            assert np.abs(d[strong]).max() < 1e-9
+            # ... the unwrap invariant on every bin (no jump above pi along frequency) ...
+            assert np.abs(np.diff(s, axis=0)).max() <= np.pi + 1e-9
+            # ... and equality of the VALUES on the frames where the unwrap has no close calls: every bin strong, and no
+            # neighbouring pair of wrapped angles within 1e-6 of a +-pi step (where a 1e-12 error flips a 2*pi decision)
+            _, _, ang = orc.spectrogram(x, fs=16000.0, nperseg=256, window="hann", noverlap=128, mode="angle")
+            step = np.abs(np.diff(ang, axis=0))
+            solid = (mag > 1e-6 * mag.max()).all(axis=0) & (np.abs(step - np.pi) > 1e-6).all(axis=0)
+            assert solid.sum() >= 3
+            assert np.abs(s[:, solid] - so[:, solid]).max() < 1e-8
 
 
 def test_sweep_golden(sp):

@@ -29,6 +29,22 @@ def test_abi_exports_every_declared_symbol():
     assert lib.sg_version() == 101
 
 
+def test_host_shim_under_address_and_ub_sanitizers():
+    """the host side of the ABI (argument triage, f / t vectors, mel bank construction, jet table, error
+    strings -- csrc/host_shim.cpp, the very file linked into libspectro.so) built with g++ -fsanitize=address,undefined
+    and driven by tests/asan_driver.cpp.  GPU sanitizers are not available on the pool; this is the CPU build."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("spectro_build", os.path.join(PKG, "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    exe = mod.build_sanitizer_driver()
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    env.pop("LD_PRELOAD", None)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "checks passed under AddressSanitizer" in r.stdout and "runtime error" not in r.stderr
+
+
 def test_abi_host_side_helpers_without_gpu():
     from spectro import _capi
     import scipy.fft

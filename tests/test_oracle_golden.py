@@ -115,6 +115,29 @@ def test_g2_cfg1_extended(tag, dt):
     assert _rel(s, ref) <= tol
 
 
+@pytest.mark.parametrize("mode", ["angle", "phase"])
+def test_g2_angle_and_phase_modes(mode):
+    """scipy's 'angle' and 'phase' (= angle unwrapped ALONG FREQUENCY, scipy:990-992) on the f64 signal: the oracle must
+    agree with scipy's stored result modulo 2*pi wherever the bin carries energy, and exactly on the frames whose unwrap has
+    no close calls (no neighbouring wrapped angles within 1e-6 of a +-pi step)."""
+    g = load_golden("g2_cfg1_extended.npz")
+    x = cfg1_signal()
+    kw = dict(nperseg=512, window="hann", noverlap=256)
+    f, t, s = orc.spectrogram(x, fs=16000.0, mode=mode, **kw)
+    ref = g[f"hann256_{mode}_float64__Sxx"]
+    mag = g["hann256_mag_float64__Sxx"]
+    ang = g["hann256_angle_float64__Sxx"]
+    assert s.shape == ref.shape
+    strong = mag > 1e-6 * mag.max()
+    d = np.angle(np.exp(1j * (s - ref)))
+    assert np.abs(d[strong]).max() < 1e-8
+    if mode == "phase":
+        solid = strong.all(axis=0) & (np.abs(np.abs(np.diff(ang, axis=0)) - np.pi) > 1e-6).all(axis=0)
+        assert solid.sum() >= 3
+        assert np.abs(s[:, solid] - ref[:, solid]).max() < 1e-8
+        assert np.abs(np.diff(s, axis=0)).max() <= np.pi + 1e-9
+
+
 @pytest.mark.parametrize("tag", ["ext", "ref"])
 def test_g3_cfg2_sampled(tag):
     g = load_golden("g3_cfg2_sampled.npz")
