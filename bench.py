@@ -50,9 +50,9 @@ N_BUFFER_SETS = 4                               # rotate so the 256 MiB Infinity
 # Arithmetic of one frame.  ALGORITHMIC: real FFT 2.5 n log2 n = 25 600 + detrend/window 3 n + epilogue
 # 4 (n/2 + 1) = 30 724 flop.  EXECUTED by stft1024_r8x3_kernel per wave = per frame (instruction mix of the frame loop,
 # profiles/r02_isa_mix_r8x3.txt, from `hipcc -S`): 320 VALU instructions = 366 issue slots (v_pk_add_f32 and v_mov_b64
-# hold the SIMD for two), 101 of them FMAs -> 423 flop per lane x 64 lanes.
+# hold the SIMD for two), 101 of them FMAs -> 101*2 + 163 + 32*2 = 429 flop per lane x 64 lanes.
 FLOP_PER_FRAME_ALGORITHMIC = 30724
-FLOP_PER_FRAME_EXECUTED = 423 * 64
+FLOP_PER_FRAME_EXECUTED = 429 * 64
 VALU_ISSUE_SLOTS_PER_FRAME = 366
 CYCLES_PER_SLOT = 2                              # a wave64 VALU instruction occupies its SIMD-32 for 2 cycles (MI355X_MICROARCH.md)
 SCLK_MAX_MHZ = 2400.0

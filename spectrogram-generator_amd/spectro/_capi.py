@@ -127,6 +127,8 @@ def ensure_device(device: int | None = None):
         if _device_ready is not None:
             return _device_ready
         device = int(os.environ.get("SPECTRO_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    if _device_ready is not None and int(device) != _device_ready:
+        device_pool_clear()                     # pooled blocks belong to the device they were allocated on
     check(lib().sg_init(int(device)))
     _device_ready = int(device)
     return _device_ready
@@ -145,19 +147,68 @@ def device_pci_bus_id() -> str:
     return buf.value.decode()
 
 
+# Device memory comes from a small size-bucketed pool: every shim call used to pay hipMalloc + hipFree, and hipFree
+# synchronises the whole device -- the dominant cost of a GUI-sized call.  Buffers are recycled in issue order on the
+# stream they were used on (the shim's calls are stream-ordered on the default stream; the pipelined path keeps its own
+# per-stream workspace), so a recycled block is never touched by a kernel that is still running on it.
+_POOL_MAX_BYTES = int(os.environ.get("SPECTRO_POOL_BYTES", str(2 << 30)))      # 0 disables pooling
+_pool_free: dict = {}             # capacity -> [ptr, ...]
+_pool_bytes = 0
+_pool_lock = threading.Lock()
+
+
+def _bucket(nbytes: int) -> int:
+    """capacity class: powers of two up to 1 MiB, then multiples of 1 MiB (little slack on big spectra)"""
+    n = max(int(nbytes), 256)
+    if n <= (1 << 20):
+        return 1 << (n - 1).bit_length()
+    return (n + (1 << 20) - 1) & ~((1 << 20) - 1)
+
+
+def device_pool_clear():
+    """hipFree every pooled block (memory-tight callers, device switches, tests)."""
+    global _pool_bytes
+    with _pool_lock:
+        for ptrs in _pool_free.values():
+            for p in ptrs:
+                lib().sg_free(C.c_void_p(p))
+        _pool_free.clear()
+        _pool_bytes = 0
+
+
 class DeviceBuffer:
-    """Owning handle of raw device memory obtained through sg_malloc."""
+    """Owning handle of raw device memory obtained through sg_malloc (recycled through the pool above)."""
 
     def __init__(self, nbytes: int):
+        global _pool_bytes
         self.nbytes = int(nbytes)
+        self.capacity = _bucket(self.nbytes) if _POOL_MAX_BYTES else max(self.nbytes, 1)
+        if _POOL_MAX_BYTES:
+            with _pool_lock:
+                free = _pool_free.get(self.capacity)
+                if free:
+                    self.ptr = free.pop()
+                    _pool_bytes -= self.capacity
+                    return
         p = C.c_void_p()
-        check(lib().sg_malloc(C.byref(p), self.nbytes))
+        rc = lib().sg_malloc(C.byref(p), self.capacity)
+        if rc != SG_OK and _POOL_MAX_BYTES:       # out of memory with blocks parked in the pool: release them and retry once
+            device_pool_clear()
+            rc = lib().sg_malloc(C.byref(p), self.capacity)
+        check(rc)
         self.ptr = p.value
 
     def free(self):
+        global _pool_bytes
         if getattr(self, "ptr", None):
-            lib().sg_free(C.c_void_p(self.ptr))
-            self.ptr = None
+            ptr, self.ptr = self.ptr, None
+            if _POOL_MAX_BYTES:
+                with _pool_lock:
+                    if _pool_bytes + self.capacity <= _POOL_MAX_BYTES:
+                        _pool_free.setdefault(self.capacity, []).append(ptr)
+                        _pool_bytes += self.capacity
+                        return
+            lib().sg_free(C.c_void_p(ptr))
 
     def __del__(self):
         try:
