@@ -245,6 +245,24 @@ int sg_stft_mel(const sg_plan* plan, const float* x_dev, int64_t n_samples, int6
                 const float* packed_weights_dev, int weights_n_bins, int n_mels, const int* tile_k_lo,
                 const int* tile_k_hi, int log_scale, float* mel_dev, int64_t out_clip_stride, void* stream);
 
+/*
+ * The same product through a BAND-SPARSE form of the bank (the default of the Python shim for triangular banks): a
+ * triangular filterbank touches every bin with exactly two bands, so a frame's mel spectrum is ~2 n_bins multiply-adds, not
+ * the n_bins * n_mels of the dense product.  sg_mel_sparse_pack (host) cuts the hull of every band's non-zero bins into work
+ * items of <= 8 bins: item_start[64*IPL], item_w[8][64*IPL] (zero padded), band_first / band_count[n_mels] (a band's items are
+ * adjacent), *items_per_lane = IPL in 1..4; the caller provides room for IPL = 4 (256 ints, 2048 floats) and uploads the
+ * first 64*IPL resp. 8*64*IPL entries.  SG_ERR_UNSUPPORTED when the bank needs more than 256 items (a dense bank) or has more
+ * than 128 bands: use sg_stft_mel.  sg_stft_mel_sparse runs the nfft-1024 register kernel with that epilogue: every wave
+ * leaves the PSD row in LDS, gathers its items against weights held in registers and writes mel_dev[n_clips][n_frames][n_mels]
+ * (10*log10(max(x, 1e-10)) with log_scale); no workgroup barrier, no frame tile.  Same plan / input requirements as sg_stft_mel.
+ */
+int sg_mel_sparse_pack(const double* weights_host, int n_bins, int n_mels, int* items_per_lane, int32_t* item_start,
+                       float* item_w, int32_t* band_first, int32_t* band_count);
+int sg_stft_mel_sparse(const sg_plan* plan, const float* x_dev, int64_t n_samples, int64_t clip_stride, int n_clips,
+                       const int32_t* item_start_dev, const float* item_w_dev, const int32_t* band_first_dev,
+                       const int32_t* band_count_dev, int items_per_lane, int n_mels, int log_scale, float* mel_dev,
+                       int64_t out_clip_stride, void* stream);
+
 /* ---- timing helper used by bench.py (HIP events on `stream`) ---------- */
 /* Runs sg_stft `iters` times back to back between two hipEvents and returns the
  * average milliseconds per launch.  Synchronises `stream`. */

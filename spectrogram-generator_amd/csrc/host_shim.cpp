@@ -118,6 +118,45 @@ int sg_mel_tile_ranges(const double* weights_host, int n_bins, int n_mels, int* 
     return SG_OK;
 }
 
+int sg_mel_sparse_pack(const double* weights_host, int n_bins, int n_mels, int* items_per_lane, int32_t* item_start,
+                       float* item_w, int32_t* band_first, int32_t* band_count) {
+    if (!weights_host || !items_per_lane || !item_start || !item_w || !band_first || !band_count || n_bins < 1 || n_mels < 1) {
+        set_error("sg_mel_sparse_pack: bad argument");
+        return SG_ERR_ARG;
+    }
+    *items_per_lane = 0;
+    if (n_mels > 128) { set_error("sg_mel_sparse_pack: more than 128 bands"); return SG_ERR_UNSUPPORTED; }
+    // work items: the hull [lo, hi) of a band's non-zero bins cut into pieces of 8 bins
+    struct Item { int start, band; };
+    std::vector<Item> items;
+    for (int j = 0; j < n_mels; ++j) {
+        int lo = n_bins, hi = 0;
+        for (int k = 0; k < n_bins; ++k)
+            if (weights_host[static_cast<size_t>(k) * n_mels + j] != 0.0) { if (k < lo) lo = k; hi = k + 1; }
+        band_first[j] = static_cast<int32_t>(items.size());
+        int n = 0;
+        for (int s = lo; s < hi; s += 8, ++n) items.push_back({s, j});
+        band_count[j] = n;
+        if (items.size() > 256) {
+            set_error("sg_mel_sparse_pack: the bank needs more than 256 work items (a dense bank: use sg_mel / sg_stft_mel)");
+            return SG_ERR_UNSUPPORTED;
+        }
+    }
+    const int ipl = items.empty() ? 1 : static_cast<int>((items.size() + 63) / 64);
+    const int slots = 64 * ipl;
+    for (int i = 0; i < slots; ++i) {
+        const bool live = i < static_cast<int>(items.size());
+        item_start[i] = live ? items[i].start : 0;
+        for (int c = 0; c < 8; ++c) {
+            const int k = live ? items[i].start + c : 0;
+            item_w[static_cast<size_t>(c) * slots + i] =
+                (live && k < n_bins) ? static_cast<float>(weights_host[static_cast<size_t>(k) * n_mels + items[i].band]) : 0.f;
+        }
+    }
+    *items_per_lane = ipl;
+    return SG_OK;
+}
+
 int sg_jet_lut(uint8_t* rgba_host) {
     if (!rgba_host) { set_error("null pointer"); return SG_ERR_ARG; }
     // matplotlib _cm.py 'jet' segment data: (x, y) breakpoints, linear in between

@@ -393,6 +393,28 @@ int sg_stft_db(const sg_plan* plan, const float* x_dev, int64_t n_samples, int64
     return fold_minmax_f32(static_cast<const float*>(parts), n_parts, mm_dev, s);
 }
 
+int sg_stft_mel_sparse(const sg_plan* plan, const float* x_dev, int64_t n_samples, int64_t clip_stride, int n_clips,
+                       const int32_t* item_start_dev, const float* item_w_dev, const int32_t* band_first_dev,
+                       const int32_t* band_count_dev, int items_per_lane, int n_mels, int log_scale, float* mel_dev,
+                       int64_t out_clip_stride, void* stream) {
+    if (!plan) { set_error("null plan"); return SG_ERR_ARG; }
+    if (plan->kernel != Kernel::R8X3 || plan->mode != SG_MODE_PSD) {
+        set_error("fused STFT+mel needs an f32 nperseg = nfft = 1024 PSD plan (kernel r8x3)");
+        return SG_ERR_UNSUPPORTED;
+    }
+    if (items_per_lane < 1 || items_per_lane > 4 || n_mels < 1 || n_mels > 128 || n_clips < 0 || n_samples < 0) { set_error("bad sizes"); return SG_ERR_ARG; }
+    const int64_t n_frames = n_samples < plan->nperseg ? 0 : (n_samples - plan->nperseg) / plan->hop + 1;
+    if (n_frames == 0 || n_clips == 0) return SG_OK;
+    if (!x_dev || !mel_dev || !item_start_dev || !item_w_dev || !band_first_dev || !band_count_dev) { set_error("null device pointer"); return SG_ERR_ARG; }
+    if (n_clips > 1 && (clip_stride < n_samples || out_clip_stride < n_frames * n_mels)) { set_error("bad strides"); return SG_ERR_ARG; }
+    StftArgs a{};
+    a.x = x_dev; a.in_i16 = 0; a.n_samples = n_samples; a.clip_stride = clip_stride; a.n_clips = n_clips;
+    a.out = mel_dev; a.out_clip_stride = out_clip_stride; a.n_frames = n_frames; a.stream = static_cast<hipStream_t>(stream);
+    a.mel_ipl = items_per_lane; a.mel_start = item_start_dev; a.mel_w = item_w_dev; a.mel_first = band_first_dev;
+    a.mel_count = band_count_dev; a.n_mels = n_mels; a.log_scale = log_scale;
+    return launch_r8x3(*plan, a);
+}
+
 int sg_time_stft(const sg_plan* plan, const void* x_dev, int64_t n_samples, int64_t clip_stride, int n_clips,
                  void* out_dev, int64_t out_clip_stride, void* stream, int iters, float* ms_per_launch) {
     if (!ms_per_launch || iters < 1) { set_error("bad argument"); return SG_ERR_ARG; }

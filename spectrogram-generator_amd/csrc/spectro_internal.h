@@ -53,11 +53,13 @@ struct StftArgs {
     int band_mode, k_lo, k_hi;              // band-power variant: only per-frame sums are written
     int db_mode; float inv_base; void* mm_parts;   // r8x3 dB-image variant: bins [k_lo,k_hi] as 10*log10(clip(S*inv_base,0,1)+1e-12),
                                                    // per-wave (min, max) pairs into mm_parts[r8x3_grid_waves]
+    int mel_ipl;                                   // r8x3 mel variant: work items per lane (1..4) of a band-sparse bank, 0 = off
+    const int* mel_start; const float* mel_w; const int* mel_first; const int* mel_count; int n_mels, log_scale;
     hipStream_t stream;
 };
 
 int launch_r8x3(const sg_plan& p, const StftArgs& a);
-int r8x3_grid_waves(const sg_plan& p, int64_t total_frames);   // waves (= min/max partials of the dB variant) of a launch
+int r8x3_grid_waves(const sg_plan& p, int64_t total_frames, bool mel = false);   // waves (= min/max partials of the dB variant) of a launch
 // epilogue.hip: per-(device, stream) scratch of 256 KiB for reduction partials; fold of n (min, max) float pairs into mm[2]
 void* reduction_scratch(hipStream_t s);
 int fold_minmax_f32(const float* parts, int n_parts, float* mm_dev, hipStream_t s);

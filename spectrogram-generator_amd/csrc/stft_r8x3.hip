@@ -92,6 +92,12 @@ struct R8Params {
     int k_lo, k_hi;        // OUT_BAND, OUT_DB_BAND
     float inv_base;        // OUT_DB*: 1 / (global_max + 1e-20)
     float2* mm_parts;      // OUT_DB*: [n_waves] (min, max) of the dB values a wave wrote
+    // OUT_MEL: the band-sparse mel bank of sg_mel_sparse_pack (host_shim.cpp)
+    const int* mel_start;      // [64*IPL]     first bin of work item i (item = up to 8 consecutive bins of one band)
+    const float* mel_w;        // [8][64*IPL]  its weights, zero padded
+    const int* mel_first;      // [n_mels]     first item of band j
+    const int* mel_count;      // [n_mels]     items of band j
+    int n_mels, log_scale;
 };
 
 // What a frame leaves in HBM.
@@ -100,7 +106,15 @@ struct R8Params {
 //   OUT_DB_FULL/_BAND  10*log10(clip(S/(gmax+1e-20), 0, 1) + 1e-12) of bins [k_lo, k_hi] (PlotEngine.py:126-129 with a
 //                      caller-supplied global_max, :110) plus the wave's min / max of what it wrote, so that the min-max
 //                      rescale of :130-131 needs no further pass over the spectrum
-enum { OUT_PSD = 0, OUT_MAG = 1, OUT_BAND = 2, OUT_DB_FULL = 3, OUT_DB_BAND = 4 };
+//   OUT_MEL1..4        the mel spectrum [n_mels] of the PSD row through a band-sparse bank (cfg3; IPL = 1..4 work items per lane):
+//                      a triangular bank touches every bin with exactly two bands, so the contraction is ~1000 multiply-adds per
+//                      frame, not the 41 040 of the dense product (or the ~20 000 a block-sparse MFMA form issues).  The wave
+//                      leaves its PSD row in LDS, every lane gathers the <= 8 bins of its work items against weights it keeps in
+//                      registers, the partial sums of a band (adjacent items) are added by the lane that owns the band.
+//                      No workgroup barrier, no 16-frame tile: the kernel keeps the occupancy and the run structure of OUT_BAND.
+enum { OUT_PSD = 0, OUT_MAG = 1, OUT_BAND = 2, OUT_DB_FULL = 3, OUT_DB_BAND = 4, OUT_MEL1 = 5, OUT_MEL2 = 6, OUT_MEL3 = 7, OUT_MEL4 = 8 };
+constexpr int kMelRow = 544;     // floats of a wave's PSD row in LDS: 513 bins + the 7 a last item may read past them, rounded up
+constexpr int kMelPart = 256;    // partial sums: one per work item (64 * IPL <= 256)
 
 __device__ __forceinline__ float wave_min_f(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
@@ -121,11 +135,16 @@ __device__ __forceinline__ float wave_max_f(float v) {
 // (clip, frame) index space, runs differ by at most one frame, so there is no tail of half-empty rounds.
 // Window and twiddles stay in VGPRs (SG_TW_LDS=0, ~118 VGPRs = 4 waves/SIMD); SG_TW_LDS=1 moves the twiddles to a
 // 9 KiB workgroup-shared LDS table (83 VGPRs = 5 waves/SIMD).
+constexpr int occupancy_for(int out) { return out >= OUT_MEL1 ? (kOccupancy < 3 ? kOccupancy : 3) : kOccupancy; }   // OUT_MEL: +8*IPL weight registers
+
 template <typename TIn, bool ALIGNED, bool DETREND, int OUT, int H>
-__global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_kernel(const R8Params p) {
+__global__ __launch_bounds__(64 * kWavesPerWg, occupancy_for(OUT)) void stft1024_r8x3_kernel(const R8Params p) {
     constexpr bool BAND = OUT == OUT_BAND;
     constexpr bool DB = OUT == OUT_DB_FULL || OUT == OUT_DB_BAND;
+    constexpr bool MEL = OUT >= OUT_MEL1;
+    constexpr int IPL = MEL ? OUT - OUT_MEL1 + 1 : 1;        // work items per lane
     constexpr int MODE = OUT == OUT_MAG ? 1 : 0;
+    __shared__ __attribute__((aligned(16))) float mel_lds[MEL ? kWavesPerWg * (kMelRow + kMelPart) : 1];
     __shared__ __attribute__((aligned(16))) float2 lds[kWavesPerWg * kSlab + (SG_TW_LDS ? 18 * 64 : 0)];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -178,7 +197,28 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
     }
     const float r0 = (MODE == 0 && lane == 0) ? 0.5f : 1.0f;
     float vmin = INFINITY, vmax = -INFINITY;         // OUT_DB*: this lane's extrema of the dB values written
-    const int row_len = DB ? p.k_hi - p.k_lo + 1 : kBins;
+    const int row_len = DB ? p.k_hi - p.k_lo + 1 : (MEL ? p.n_mels : kBins);
+    // OUT_MEL: this wave's PSD row and partial sums in LDS; the lane's work items (first bin, 8 weights) and the items of the
+    // bands it owns (band = lane + 64 * pass) stay in registers for the whole run
+    float* const mrow = mel_lds + wave * (kMelRow + kMelPart);
+    float* const mpart = mrow + kMelRow;
+    float mw[IPL][8];
+    const float* mgather[IPL];
+    int bfirst[2] = {0, 0}, bcount[2] = {0, 0};
+    if (MEL) {
+#pragma unroll
+        for (int i = 0; i < IPL; ++i) {
+            mgather[i] = mrow + p.mel_start[lane + 64 * i];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) mw[i][c] = p.mel_w[(c * IPL + i) * 64 + lane];
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int j = lane + 64 * q;
+            if (j < p.n_mels) { bfirst[q] = p.mel_first[j]; bcount[q] = p.mel_count[j]; }
+        }
+        if (lane < kMelRow - kBins) mrow[kBins + lane] = 0.f;        // the slots behind bin 512 meet zero weights: keep them finite
+    }
 
     int64_t g = p.total_frames * lw / p.n_waves;
     const int64_t g_end = p.total_frames * (lw + 1) / p.n_waves;
@@ -264,6 +304,8 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
                         vmin = fminf(vmin, d);
                         vmax = fmaxf(vmax, d);
                     }
+                } else if (MEL) {
+                    mrow[k] = v;
                 } else {
                     orow[k] = v;
                 }
@@ -303,6 +345,25 @@ __global__ __launch_bounds__(64 * kWavesPerWg, kOccupancy) void stft1024_r8x3_ke
                 const float tot = wave_sum(band);
                 if (lane == 0) *orow = tot;
                 orow += 1;
+            } else if (MEL) {
+                wave_lds_fence();                                  // the row is complete
+#pragma unroll
+                for (int i = 0; i < IPL; ++i) {                    // <= 8 bins of one band per work item
+                    float acc = mw[i][0] * mgather[i][0];
+#pragma unroll
+                    for (int c = 1; c < 8; ++c) acc = fmaf(mw[i][c], mgather[i][c], acc);
+                    mpart[lane + 64 * i] = acc;
+                }
+                wave_lds_fence();
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {                      // the lane that owns band lane + 64 q adds its items
+                    if (q == 1 && p.n_mels <= 64) break;
+                    float v = 0.f;
+                    for (int t = 0; t < bcount[q]; ++t) v += mpart[bfirst[q] + t];
+                    if (p.log_scale) v = 3.01029995663981195f * __log2f(fmaxf(v, 1e-10f));      // 10 log10 through v_log_f32
+                    if (lane + 64 * q < p.n_mels) orow[lane + 64 * q] = v;
+                }
+                orow += row_len;
             } else {
                 orow += row_len;
             }
@@ -379,6 +440,16 @@ int launch_out(const R8Params& prm, int n_wg, hipStream_t s, int out) {
         if (out == OUT_DB_FULL) return launch_one<TIn, ALIGNED, DETREND, OUT_DB_FULL>(prm, n_wg, s);
         if (out == OUT_DB_BAND) return launch_one<TIn, ALIGNED, DETREND, OUT_DB_BAND>(prm, n_wg, s);
     }
+    if constexpr (std::is_same<TIn, float>::value && ALIGNED) {      // the mel form: aligned float input, hop 256 slides, others reload
+        const bool slide = prm.hop == 256;
+        switch (out) {
+            case OUT_MEL1: return slide ? launch_h<TIn, ALIGNED, DETREND, OUT_MEL1, 2>(prm, n_wg, s) : launch_h<TIn, ALIGNED, DETREND, OUT_MEL1, 0>(prm, n_wg, s);
+            case OUT_MEL2: return slide ? launch_h<TIn, ALIGNED, DETREND, OUT_MEL2, 2>(prm, n_wg, s) : launch_h<TIn, ALIGNED, DETREND, OUT_MEL2, 0>(prm, n_wg, s);
+            case OUT_MEL3: return slide ? launch_h<TIn, ALIGNED, DETREND, OUT_MEL3, 2>(prm, n_wg, s) : launch_h<TIn, ALIGNED, DETREND, OUT_MEL3, 0>(prm, n_wg, s);
+            case OUT_MEL4: return slide ? launch_h<TIn, ALIGNED, DETREND, OUT_MEL4, 2>(prm, n_wg, s) : launch_h<TIn, ALIGNED, DETREND, OUT_MEL4, 0>(prm, n_wg, s);
+            default: break;
+        }
+    }
     set_error("r8x3: output form %d is not built for this input type", out);
     return SG_ERR_UNSUPPORTED;
 }
@@ -394,8 +465,8 @@ int launch_in(const R8Params& prm, int n_wg, hipStream_t s, bool aligned, bool d
 }  // namespace
 
 // persistent grid: kOccupancy waves per SIMD on every CU, but never runs shorter than kMinRun frames
-int r8x3_grid_waves(const sg_plan& p, int64_t total_frames) {
-    int occ = kOccupancy;
+int r8x3_grid_waves(const sg_plan& p, int64_t total_frames, bool mel) {
+    int occ = mel ? occupancy_for(OUT_MEL1) : kOccupancy;
     if (const char* e = getenv("SPECTRO_R8_OCC")) { const int v = atoi(e); if (v >= 1 && v <= kOccupancy) occ = v; }   // tuning aid
     int64_t n_waves = static_cast<int64_t>(p.n_cu) * 4 * occ;
     const int64_t by_work = (total_frames + kMinRun - 1) / kMinRun;
@@ -412,7 +483,7 @@ int launch_r8x3(const sg_plan& p, const StftArgs& a) {
     prm.n_frames = static_cast<int>(a.n_frames);
     prm.hop = p.hop;
     prm.total_frames = a.n_frames * a.n_clips;
-    prm.n_waves = r8x3_grid_waves(p, prm.total_frames);
+    prm.n_waves = r8x3_grid_waves(p, prm.total_frames, a.mel_ipl > 0);
     const int n_wg = (prm.n_waves + kWavesPerWg - 1) / kWavesPerWg;
     prm.out = static_cast<float*>(a.out);
     prm.out_clip_stride = a.out_clip_stride;
@@ -428,12 +499,22 @@ int launch_r8x3(const sg_plan& p, const StftArgs& a) {
         prm.inv_base = a.inv_base;
         prm.mm_parts = static_cast<float2*>(a.mm_parts);
     }
+    if (a.mel_ipl > 0) {
+        if (p.mode != SG_MODE_PSD || a.mel_ipl > 4 || !a.mel_start || !a.mel_w || !a.mel_first || !a.mel_count || a.in_i16) {
+            set_error("r8x3: the mel form needs a psd plan, float input and a band-sparse bank of at most 256 work items");
+            return SG_ERR_ARG;
+        }
+        out = OUT_MEL1 + a.mel_ipl - 1;
+        prm.mel_start = a.mel_start; prm.mel_w = a.mel_w; prm.mel_first = a.mel_first; prm.mel_count = a.mel_count;
+        prm.n_mels = a.n_mels; prm.log_scale = a.log_scale;
+    }
     const bool detrend = p.detrend == SG_DETREND_CONSTANT;
     if (a.in_i16) {
         const bool aligned = (p.hop % 2 == 0) && (a.clip_stride % 2 == 0) && (reinterpret_cast<uintptr_t>(a.x) % 4 == 0);
         return launch_in<int16_t>(prm, n_wg, a.stream, aligned, detrend, out);
     }
     const bool aligned = (p.hop % 2 == 0) && (a.clip_stride % 2 == 0) && (reinterpret_cast<uintptr_t>(a.x) % 8 == 0);
+    if (a.mel_ipl > 0 && !aligned) { set_error("r8x3: the mel form needs an even hop / clip stride and 8-byte aligned input"); return SG_ERR_UNSUPPORTED; }
     return launch_in<float>(prm, n_wg, a.stream, aligned, detrend, out);
 }
 

@@ -36,6 +36,22 @@ class MelBank:
                                                     packed.ctypes.data_as(C.POINTER(C.c_float))))
         self._dev = _capi.DeviceBuffer(packed.nbytes)
         self._dev.upload(packed)
+        # band-sparse form for the fused kernel (None for a bank that is not band-limited enough: the MFMA kernel takes it)
+        self._sparse = None
+        ipl = C.c_int(0)
+        start, wts = np.zeros(256, np.int32), np.zeros(8 * 256, np.float32)
+        first, count = np.zeros(self.n_mels, np.int32), np.zeros(self.n_mels, np.int32)
+        rc = _capi.lib().sg_mel_sparse_pack(w.ctypes.data_as(C.POINTER(C.c_double)), self.n_bins, self.n_mels, C.byref(ipl),
+                                            start.ctypes.data_as(C.POINTER(C.c_int32)), wts.ctypes.data_as(C.POINTER(C.c_float)),
+                                            first.ctypes.data_as(C.POINTER(C.c_int32)), count.ctypes.data_as(C.POINTER(C.c_int32)))
+        if rc == _capi.SG_OK:
+            n = 64 * ipl.value
+            bufs = [_capi.DeviceBuffer(max(a.nbytes, 4)) for a in (start[:n], wts[:8 * n], first, count)]
+            for b, a in zip(bufs, (start[:n], wts[:8 * n], first, count)):
+                b.upload(np.ascontiguousarray(a))
+            self._sparse = (ipl.value, bufs)
+        elif rc != _capi.SG_ERR_UNSUPPORTED:
+            _capi.check(rc)
         _capi.stream_sync()
 
     @property
@@ -81,12 +97,31 @@ class MelBank:
             d_out.free()
         return np.moveaxis(out, 1, 2)
 
-    def stft_mel_ptr(self, plan, x_ptr, n_samples, clip_stride, n_clips, out_ptr, out_clip_stride, log_scale=False, stream=None):
+    def stft_mel_ptr(self, plan, x_ptr, n_samples, clip_stride, n_clips, out_ptr, out_clip_stride, log_scale=False, stream=None,
+                     kernel=None):
+        """``kernel``: None = the band-sparse epilogue when the bank has one (every triangular bank), else the MFMA tile
+        kernel; "sparse" / "mfma" force one (SPECTRO_FUSED_MFMA=1 in the environment forces "mfma" too)."""
         if self.n_bins != plan.n_bins:
             raise ValueError(f"mel bank built for nfft {self.nfft} ({self.n_bins} bins), plan has {plan.n_bins} bins")
+        import os
+        if kernel is None:
+            kernel = "mfma" if (self._sparse is None or os.environ.get("SPECTRO_FUSED_MFMA") == "1") else "sparse"
+        if kernel == "sparse":
+            if self._sparse is None:
+                raise NotImplementedError("this bank has no band-sparse form (more than 256 work items)")
+            ipl, (b_start, b_w, b_first, b_count) = self._sparse
+            _capi.check(_capi.lib().sg_stft_mel_sparse(plan.handle, C.c_void_p(x_ptr), int(n_samples), int(clip_stride), int(n_clips),
+                                                       C.c_void_p(b_start.ptr), C.c_void_p(b_w.ptr), C.c_void_p(b_first.ptr),
+                                                       C.c_void_p(b_count.ptr), ipl, self.n_mels, int(bool(log_scale)),
+                                                       C.c_void_p(out_ptr), int(out_clip_stride), C.c_void_p(stream)))
+            return
         _capi.check(_capi.lib().sg_stft_mel(plan.handle, C.c_void_p(x_ptr), int(n_samples), int(clip_stride), int(n_clips),
                                             C.c_void_p(self._dev.ptr), self.n_bins, self.n_mels, self._k_lo, self._k_hi,
                                             int(bool(log_scale)), C.c_void_p(out_ptr), int(out_clip_stride), C.c_void_p(stream)))
 
     def close(self):
         self._dev.free()
+        if self._sparse is not None:
+            for b in self._sparse[1]:
+                b.free()
+            self._sparse = None

@@ -80,6 +80,41 @@ int main() {
                 CHECK(packed[static_cast<size_t>(m) * kpad + k] == want);
             }
     }
+    // ---- band-sparse packing: every non-zero weight lands in exactly one work item, buffers of the documented size only ----
+    for (const auto& c : cfgs) {
+        const int nfft = c[0], nm = c[1], nb = nfft / 2 + 1;
+        if (nm > 128) continue;
+        std::vector<double> w(static_cast<size_t>(nb) * nm);
+        CHECK(sg_mel_weights(nfft, 48000.0, nm, 0.0, 24000.0, w.data()) == SG_OK);
+        std::vector<int32_t> start(256), first(nm), count(nm);
+        std::vector<float> iw(8 * 256);
+        int ipl = -1;
+        const int rc = sg_mel_sparse_pack(w.data(), nb, nm, &ipl, start.data(), iw.data(), first.data(), count.data());
+        if (rc == SG_ERR_UNSUPPORTED) { CHECK(ipl == 0); continue; }          // e.g. 33 bands over 2049 bins: too many items
+        CHECK(rc == SG_OK && ipl >= 1 && ipl <= 4);
+        const int slots = 64 * ipl;
+        std::vector<double> back(static_cast<size_t>(nb) * nm, 0.0);
+        for (int j = 0; j < nm; ++j) {
+            CHECK(first[j] >= 0 && count[j] >= 0 && first[j] + count[j] <= slots);
+            for (int t = 0; t < count[j]; ++t) {
+                const int i = first[j] + t;
+                for (int cc = 0; cc < 8; ++cc) {
+                    const int k = start[i] + cc;
+                    const float v = iw[static_cast<size_t>(cc) * slots + i];
+                    if (k < nb) back[static_cast<size_t>(k) * nm + j] += v; else CHECK(v == 0.f);
+                }
+            }
+        }
+        for (size_t q = 0; q < back.size(); ++q) CHECK(static_cast<float>(w[q]) == static_cast<float>(back[q]));
+    }
+    {
+        std::vector<double> dense(513 * 16, 0.5);                                  // a dense bank has no sparse form
+        std::vector<int32_t> start(256), first(16), count(16);
+        std::vector<float> iw(8 * 256);
+        int ipl = -1;
+        CHECK(sg_mel_sparse_pack(dense.data(), 513, 16, &ipl, start.data(), iw.data(), first.data(), count.data()) == SG_ERR_UNSUPPORTED);
+        CHECK(sg_mel_sparse_pack(nullptr, 513, 16, &ipl, start.data(), iw.data(), first.data(), count.data()) == SG_ERR_ARG);
+    }
     {
         std::vector<double> w(513 * 80);
         CHECK(sg_mel_weights(1024, 48000.0, 80, 100.0, 50.0, w.data()) == SG_ERR_ARG);      // fmax <= fmin

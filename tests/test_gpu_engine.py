@@ -233,13 +233,14 @@ def test_streaming_many_small_chunks(nperseg, hop, max_chunk):
     st.close()
 
 
-@pytest.mark.parametrize("variant", ["default", "ws", "ws_cons4"])
+@pytest.mark.parametrize("variant", ["default", "mfma", "ws", "ws_cons4"])
 @pytest.mark.parametrize("hop,n_mels,detrend", [(256, 80, "constant"), (896, 40, "constant"), (130, 128, False)])
 def test_fused_stft_mel(hop, n_mels, detrend, variant, monkeypatch):
     """cfg3 fused kernel (sg_stft_mel): equals mel(oracle PSD) and the unfused sg_stft + sg_mel path, incl. a frame
     count that is not a multiple of the 16-frame tile and several clips; every kernel form the library carries."""
-    for k, v in {"default": {}, "ws": {"SPECTRO_FUSED_WS": "1"},
-                 "ws_cons4": {"SPECTRO_FUSED_WS": "1", "SPECTRO_FUSED_CONS": "4"}}[variant].items():
+    # default = the band-sparse epilogue of the register kernel; the three MFMA tile kernels stay selectable
+    for k, v in {"default": {}, "mfma": {"SPECTRO_FUSED_MFMA": "1"}, "ws": {"SPECTRO_FUSED_MFMA": "1", "SPECTRO_FUSED_WS": "1"},
+                 "ws_cons4": {"SPECTRO_FUSED_MFMA": "1", "SPECTRO_FUSED_WS": "1", "SPECTRO_FUSED_CONS": "4"}}[variant].items():
         monkeypatch.setenv(k, v)
     from oracle import mel_oracle
     from spectro import _capi, engine
@@ -252,6 +253,7 @@ def test_fused_stft_mel(hop, n_mels, detrend, variant, monkeypatch):
     if N % 2:
         x = np.ascontiguousarray(x[:, :-1])
     bank = MelBank(1024, 48000.0, n_mels, 30.0, 22000.0)
+    assert bank._sparse is not None and 1 <= bank._sparse[0] <= 4                               # work items per lane
     plan = plan_for(get_window("hann", 1024), 1024, 1024, hop, _capi.DETREND[detrend], 48000.0, 0, 0, _capi.F32)
     assert plan.kernel == "r8x3"
     _, _, s = orc.spectrogram(x, fs=48000.0, nperseg=1024, window="hann", noverlap=1024 - hop, detrend=detrend)

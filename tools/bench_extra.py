@@ -24,10 +24,17 @@ d_in = _capi.DeviceBuffer(x.nbytes)
 d_in.upload(x)
 
 
-def timed(fn, iters=20, warm=3):
+def timed(fn, iters=20, warm=3, settle_s=0.0):
+    """average seconds per call; settle_s > 0: that long of back-to-back calls first (clocks / board power as a batch job
+    holds them -- a 3-call warm-up times the idle clock)"""
     for _ in range(warm):
         fn()
     _capi.stream_sync()
+    t_s = time.perf_counter()
+    while time.perf_counter() - t_s < settle_s:
+        for _ in range(16):
+            fn()
+        _capi.stream_sync()
     t0 = time.perf_counter()
     for _ in range(iters):
         fn()
@@ -43,18 +50,21 @@ d_mel = _capi.DeviceBuffer(n_clips * nfr * 80 * 4)
 bank = MelBank(1024, 48000.0, 80, 0.0, 24000.0)
 plan.stft(d_in.ptr, N, N, n_clips, d_spec.ptr, nfr * 513)
 frames = n_clips * nfr
-t_stft = timed(lambda: plan.stft(d_in.ptr, N, N, n_clips, d_spec.ptr, nfr * 513))
-t_mel = timed(lambda: bank.apply_ptr(d_spec.ptr, frames, d_mel.ptr, True))
-t_mel_dense = timed(lambda: bank.apply_ptr(d_spec.ptr, frames, d_mel.ptr, True, dense=True))
-t_fused = timed(lambda: bank.stft_mel_ptr(plan, d_in.ptr, N, N, n_clips, d_mel.ptr, nfr * 80, True))
+t_stft = timed(lambda: plan.stft(d_in.ptr, N, N, n_clips, d_spec.ptr, nfr * 513), iters=200, settle_s=0.5)
+t_mel = timed(lambda: bank.apply_ptr(d_spec.ptr, frames, d_mel.ptr, True), iters=200, settle_s=0.5)
+t_mel_dense = timed(lambda: bank.apply_ptr(d_spec.ptr, frames, d_mel.ptr, True, dense=True), iters=100, settle_s=0.3)
+t_fused_mfma = timed(lambda: bank.stft_mel_ptr(plan, d_in.ptr, N, N, n_clips, d_mel.ptr, nfr * 80, True, kernel="mfma"), iters=200, settle_s=0.5)
+t_fused = timed(lambda: bank.stft_mel_ptr(plan, d_in.ptr, N, N, n_clips, d_mel.ptr, nfr * 80, True), iters=200, settle_s=0.5)
 steps_sparse = sum((hi - lo) // 4 for lo, hi in bank.tile_ranges)
 flops_dense = 2.0 * 513 * 80 * frames
 res["cfg3_mel"] = {
     "frames": frames, "stft_us": t_stft * 1e6, "mel_us": t_mel * 1e6, "mel_dense_us": t_mel_dense * 1e6,
     "stft_plus_mel_frames_per_s": frames / (t_stft + t_mel),
     "fused_us": t_fused * 1e6, "fused_frames_per_s": frames / t_fused,
+    "fused_kernel": "stft1024_r8x3_kernel OUT_MEL (band-sparse epilogue, %d work items per lane)" % (bank._sparse[0] if bank._sparse else 0),
     "fused_algorithmic_GBps": frames * (256 + 80) * 4 / t_fused / 1e9,
-    "fused_mfma_issued_TFLOPs": frames / 16 * steps_sparse * 2 * 16 * 16 * 4 / t_fused / 1e12,
+    "fused_mfma_tile_kernel_us": t_fused_mfma * 1e6,
+    "fused_mfma_issued_TFLOPs": frames / 16 * steps_sparse * 2 * 16 * 16 * 4 / t_fused_mfma / 1e12,
     "mel_hbm_GBps": frames * (513 + 80) * 4 / t_mel / 1e9,
     "mfma_issued_TFLOPs_sparse": frames / 16 * steps_sparse * 2 * 16 * 16 * 4 / t_mel / 1e12,
     "mfma_issued_TFLOPs_dense": frames / 16 * 5 * 129 * 2 * 16 * 16 * 4 / t_mel_dense / 1e12,
@@ -81,7 +91,7 @@ for n in (256, 512, 1024, 2048, 4096):
             i = turn[0] % NB
             turn[0] += 1
             p.stft(ins[i].ptr, N, N, n_clips, outs[i].ptr, nf * (n // 2 + 1))
-        t = timed(step, iters=8, warm=4)
+        t = timed(step, iters=max(8, int(0.05 / max(1e-5, 1e-9 * n_clips * nf * (n / 256)))), warm=4, settle_s=0.25)
         bpf = hop * 4 + (n // 2 + 1) * 4
         sweep[f"n{n}_h{hop}"] = {"kernel": p.kernel, "frames": n_clips * nf, "ms": t * 1e3, "frames_per_s": n_clips * nf / t,
                                  "algorithmic_GBps": n_clips * nf * bpf / t / 1e9}

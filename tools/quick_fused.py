@@ -36,4 +36,4 @@ def run(duration):
 
 run(0.4)
 dt = run(secs)
-print(f"fused {dt*1e6:.1f} us  {n_clips*nfr/dt/1e9:.3f} G frames/s  ({n_mels} mels, sustained {secs:g} s)")
+print(f"fused [{'mfma' if (bank._sparse is None or os.environ.get('SPECTRO_FUSED_MFMA') == '1') else 'sparse ipl=%d' % bank._sparse[0]}] {dt*1e6:.1f} us  {n_clips*nfr/dt/1e9:.3f} G frames/s  ({n_mels} mels, sustained {secs:g} s)")
