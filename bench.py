@@ -334,39 +334,57 @@ def main():
 
 def time_gather(args, plan, x, out, n_clips, n_frames, dev, same_gpu, world, rank, stream):
     """The path's one exchange, timed OUTSIDE the throughput region: every rank reduces its shard to the per-frame band
-    power (fused kernel, [clips, frames] f32) and sends it to rank 0 by direct peer sends (spectro.dist.gather_to_root);
-    with --gather-full the full spectra [clips, frames, 513] go too.  -> dict for rank 0, None elsewhere."""
+    power (fused kernel, [clips, frames] f32) and the shards are gathered -- the default product by ONE all_gather collective
+    (RCCL's most ordinary call; shards padded to the largest), the full spectra [clips, frames, 513] (--gather-full) by direct
+    peer sends to rank 0 (spectro.dist.gather_to_root).  -> dict for rank 0, None elsewhere."""
     import torch
     import torch.distributed as dist
     from spectro import dist as sdist
-    band = torch.empty((max(n_clips, 1), n_frames), device=dev, dtype=torch.float32)
+    band = torch.zeros((max(n_clips, 1), n_frames), device=dev, dtype=torch.float32)
     if n_clips:
         plan.band_power(x.data_ptr(), N_SAMPLES, N_SAMPLES, n_clips, 0, N_BINS - 1, band.data_ptr(), n_frames, stream=stream)
     torch.cuda.synchronize(dev)
     res = {}
-    for name, tens in (("band_power", band[:n_clips]),) + ((("full_spectra", out[:n_clips]),) if args.gather_full else ()):
-        send = tens.cpu() if same_gpu else tens
-        shapes = [None] * world
-        dist.all_gather_object(shapes, [tuple(send.shape)])
+
+    def best_of(fn, reps=3):
         best = None
-        for rep in range(3):
+        for _ in range(reps):
             dist.barrier()
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
-            got = sdist.gather_to_root([send], dst=0, shapes=shapes)
+            got = fn()
             torch.cuda.synchronize(dev)
-            dt = time.perf_counter() - t0
-            tt = torch.tensor([dt], device="cpu" if same_gpu else dev, dtype=torch.float64)
+            tt = torch.tensor([time.perf_counter() - t0], device="cpu" if same_gpu else dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             best = float(tt[0]) if best is None else min(best, float(tt[0]))
+        return best, got
+
+    # reduced product: all_gather of equal (padded) shards
+    counts = [None] * world
+    dist.all_gather_object(counts, int(n_clips))
+    pad = max(max(counts), 1)
+    send = torch.zeros((pad, n_frames), device="cpu" if same_gpu else dev, dtype=torch.float32)
+    send[:n_clips] = band[:n_clips].to(send.device)
+    recv = torch.empty((world * pad, n_frames), device=send.device, dtype=torch.float32)
+    t_best, _ = best_of(lambda: dist.all_gather_into_tensor(recv, send))
+    if rank == 0:
+        nbytes = (world - 1) * pad * n_frames * 4
+        ok = bool(torch.isfinite(recv).all()) and all(float(recv[r * pad:r * pad + c].abs().sum()) > 0 for r, c in enumerate(counts) if c)
+        res["band_power"] = {"gather_ms": t_best * 1e3, "bytes_in_per_rank": nbytes, "gather_GBps": nbytes / t_best / 1e9 if t_best > 0 else None,
+                             "collective": "all_gather_into_tensor", "values_ok": ok}
+    if args.gather_full:
+        sendf = out[:n_clips].cpu() if same_gpu else out[:n_clips]
+        shapes = [None] * world
+        dist.all_gather_object(shapes, [tuple(sendf.shape)])
+        t_best, got = best_of(lambda: sdist.gather_to_root([sendf], dst=0, shapes=shapes))
         if rank == 0:
             nbytes = sum(int(torch.tensor(s[0]).prod()) * 4 for r, s in enumerate(shapes) if r != 0)
             ok = all(tuple(g[0].shape) == tuple(shapes[r][0]) for r, g in enumerate(got))
-            res[name] = {"gather_ms": best * 1e3, "bytes_to_root": nbytes, "gather_GBps": nbytes / best / 1e9 if best > 0 else None,
-                         "shapes_ok": ok}
+            res["full_spectra"] = {"gather_ms": t_best * 1e3, "bytes_to_root": nbytes, "gather_GBps": nbytes / t_best / 1e9 if t_best > 0 else None,
+                                   "collective": "batched isend / irecv to rank 0", "shapes_ok": ok}
     if rank == 0:
-        res["note"] = ("after the timed region, best of 3, max over ranks; direct peer sends to rank 0 (xGMI is point-to-point, "
-                       "a one-shot gather is bounded by the root's inbound links)")
+        res["note"] = ("after the timed region, best of 3, max over ranks; xGMI is point-to-point: a one-shot gather is bounded by a "
+                       "rank's inbound links, a ring gains nothing")
         return res
     return None
 
