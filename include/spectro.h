@@ -258,6 +258,10 @@ int sg_stft_mel(const sg_plan* plan, const float* x_dev, int64_t n_samples, int6
  */
 int sg_mel_sparse_pack(const double* weights_host, int n_bins, int n_mels, int* items_per_lane, int32_t* item_start,
                        float* item_w, int32_t* band_first, int32_t* band_count);
+/* sg_mel through the band-sparse bank: mel_dev[n_frames][n_mels] from spec_dev[n_frames][n_bins] (f32), one wavefront per row. */
+int sg_mel_sparse(const float* spec_dev, int64_t n_frames, int n_bins, const int32_t* item_start_dev, const float* item_w_dev,
+                  const int32_t* band_first_dev, const int32_t* band_count_dev, int items_per_lane, int n_mels, int log_scale,
+                  float* mel_dev, void* stream);
 int sg_stft_mel_sparse(const sg_plan* plan, const float* x_dev, int64_t n_samples, int64_t clip_stride, int n_clips,
                        const int32_t* item_start_dev, const float* item_w_dev, const int32_t* band_first_dev,
                        const int32_t* band_count_dev, int items_per_lane, int n_mels, int log_scale, float* mel_dev,

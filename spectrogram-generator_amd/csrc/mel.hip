@@ -134,12 +134,132 @@ void launch_mel(const MelParams& p, unsigned grid, bool ldsw, hipStream_t s) {
     else hipLaunchKernelGGL((mel_kernel<NT, false>), dim3(grid), dim3(256), 0, s, p);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Band-sparse form (sg_mel_sparse_pack, host_shim.cpp): a triangular bank has two non-zero weights per bin, so a row's mel
+// spectrum is ~2 n_bins multiply-adds.  One wavefront per row, rows strided over a persistent grid: the row is fetched with
+// coalesced 4-byte loads one row ahead, parked in the wave's LDS row, every lane gathers the <= 8 bins of its work items against
+// weights held in registers, the lane that owns a band adds the band's (adjacent) partial sums.  HBM-read bound.
+struct MelSparseParams {
+    const float* spec;
+    int64_t n_frames;
+    int n_bins, n_mels, log_scale;
+    const int* start; const float* w; const int* first; const int* count;
+    float* out;
+};
+constexpr int kSparseWaves = 4;
+
+template <int IPL>
+__global__ __launch_bounds__(64 * kSparseWaves) void mel_sparse_kernel(const MelSparseParams p) {
+    extern __shared__ __attribute__((aligned(16))) float sl[];          // per wave: row[row_len] | part[64 * IPL]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int row_len = (p.n_bins + 8 + 15) & ~15;                       // a last item may read 7 slots past the last bin
+    float* const row = sl + wave * (row_len + 64 * IPL);
+    float* const part = row + row_len;
+    const int per_lane = (p.n_bins + 63) / 64;                            // bins lane, lane + 64, ... (<= 33 for nfft 4096)
+
+    float mw[IPL][8];
+    const float* gather[IPL];
+#pragma unroll
+    for (int i = 0; i < IPL; ++i) {
+        gather[i] = row + p.start[lane + 64 * i];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) mw[i][c] = p.w[(c * IPL + i) * 64 + lane];
+    }
+    int bfirst[2] = {0, 0}, bcount[2] = {0, 0};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int j = lane + 64 * q;
+        if (j < p.n_mels) { bfirst[q] = p.first[j]; bcount[q] = p.count[j]; }
+    }
+    for (int k = p.n_bins + lane; k < row_len; k += 64) row[k] = 0.f;     // finite slots behind the last bin (zero weights)
+
+    const int64_t n_waves = static_cast<int64_t>(gridDim.x) * kSparseWaves;
+    int64_t f = static_cast<int64_t>(blockIdx.x) * kSparseWaves + wave;
+    constexpr int kMaxPer = 9;                                            // register-resident prefetch for nfft <= 1024 (9 x 64 >= 513)
+    float nxt[kMaxPer];
+    const bool reg_path = per_lane <= kMaxPer;
+    auto fetch = [&](int64_t r) {
+        const float* const src = p.spec + (r < p.n_frames ? r : p.n_frames - 1) * p.n_bins;      // unconditional, always valid
+#pragma unroll
+        for (int m = 0; m < kMaxPer; ++m) { const int k = lane + 64 * m; nxt[m] = src[k < p.n_bins ? k : p.n_bins - 1]; }
+    };
+    if (reg_path && f < p.n_frames) fetch(f);
+    for (; f < p.n_frames; f += n_waves) {
+        if (reg_path) {
+#pragma unroll
+            for (int m = 0; m < kMaxPer; ++m) { const int k = lane + 64 * m; if (k < p.n_bins) row[k] = nxt[m]; }
+            fetch(f + n_waves);
+        } else {
+            const float* const src = p.spec + f * p.n_bins;
+            for (int k = lane; k < p.n_bins; k += 64) row[k] = src[k];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int i = 0; i < IPL; ++i) {
+            float acc = mw[i][0] * gather[i][0];
+#pragma unroll
+            for (int c = 1; c < 8; ++c) acc = fmaf(mw[i][c], gather[i][c], acc);
+            part[lane + 64 * i] = acc;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float* const orow = p.out + f * p.n_mels;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (q == 1 && p.n_mels <= 64) break;
+            float v = 0.f;
+            for (int t = 0; t < bcount[q]; ++t) v += part[bfirst[q] + t];
+            if (p.log_scale) v = 3.01029995663981195f * __log2f(fmaxf(v, 1e-10f));
+            if (lane + 64 * q < p.n_mels) orow[lane + 64 * q] = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+template <int IPL>
+int launch_sparse(const MelSparseParams& prm, int n_cu, hipStream_t s) {
+    const int row_len = (prm.n_bins + 8 + 15) & ~15;
+    const size_t lds = static_cast<size_t>(kSparseWaves) * (row_len + 64 * IPL) * sizeof(float);
+    int64_t n_wg = (prm.n_frames + kSparseWaves - 1) / kSparseWaves;
+    const int64_t cap = static_cast<int64_t>(n_cu) * 8;                   // 32 waves per CU
+    if (n_wg > cap) n_wg = cap;
+    auto kern = mel_sparse_kernel<IPL>;
+    if (lds > 64 * 1024) return SG_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(n_wg)), dim3(64 * kSparseWaves), lds, s, prm);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SG_OK : hip_fail(e, "mel_sparse launch");
+}
+
 }  // namespace
 }  // namespace sg
 
 using namespace sg;
 
 extern "C" {
+
+int sg_mel_sparse(const float* spec_dev, int64_t n_frames, int n_bins, const int32_t* item_start_dev, const float* item_w_dev,
+                  const int32_t* band_first_dev, const int32_t* band_count_dev, int items_per_lane, int n_mels, int log_scale,
+                  float* mel_dev, void* stream) {
+    if (n_frames < 0 || n_bins < 1 || n_bins > 8193 || n_mels < 1 || n_mels > 128 || items_per_lane < 1 || items_per_lane > 4) {
+        set_error("sg_mel_sparse: bad sizes");
+        return SG_ERR_ARG;
+    }
+    if (n_frames == 0) return SG_OK;
+    if (!spec_dev || !mel_dev || !item_start_dev || !item_w_dev || !band_first_dev || !band_count_dev) { set_error("null device pointer"); return SG_ERR_ARG; }
+    MelSparseParams prm{spec_dev, n_frames, n_bins, n_mels, log_scale, item_start_dev, item_w_dev, band_first_dev, band_count_dev, mel_dev};
+    int dev = 0, n_cu = 256;
+    if (hipGetDevice(&dev) == hipSuccess) { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount; }
+    auto s = static_cast<hipStream_t>(stream);
+    int rc;
+    switch (items_per_lane) {
+        case 1: rc = launch_sparse<1>(prm, n_cu, s); break;
+        case 2: rc = launch_sparse<2>(prm, n_cu, s); break;
+        case 3: rc = launch_sparse<3>(prm, n_cu, s); break;
+        default: rc = launch_sparse<4>(prm, n_cu, s); break;
+    }
+    if (rc == SG_ERR_UNSUPPORTED) set_error("sg_mel_sparse: row too long for the LDS");
+    return rc;
+}
 
 int sg_mel(const float* spec_dev, int64_t n_frames, int n_bins, const float* weights_dev, int n_mels,
            const int* tile_k_lo, const int* tile_k_hi, int log_scale, float* mel_dev, void* stream) {

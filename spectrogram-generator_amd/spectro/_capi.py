@@ -76,6 +76,7 @@ SIGNATURES = {
     "sg_stft_mel": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _i, _i, C.POINTER(_i), C.POINTER(_i), _i, _vp, _i64, _vp]),
     "sg_mel_sparse_pack": (_i, [C.POINTER(_d), _i, _i, C.POINTER(_i), C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_int32),
                                 C.POINTER(C.c_int32)]),
+    "sg_mel_sparse": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "sg_stft_mel_sparse": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i64, _vp]),
     "sg_time_stft": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _i64, _vp, _i, C.POINTER(C.c_float)]),
 }

@@ -58,13 +58,25 @@ class MelBank:
     def tile_ranges(self):
         return list(zip(self._k_lo, self._k_hi))
 
-    def apply_ptr(self, spec_ptr: int, n_rows: int, out_ptr: int, log_scale: bool = False, dense: bool = False, stream=None):
-        """``out[n_rows][n_mels] = spec[n_rows][n_bins] x W`` on raw device pointers (f32); asynchronous."""
+    def apply_ptr(self, spec_ptr: int, n_rows: int, out_ptr: int, log_scale: bool = False, dense: bool = False, stream=None,
+                  kernel=None):
+        """``out[n_rows][n_mels] = spec[n_rows][n_bins] x W`` on raw device pointers (f32); asynchronous.
+        ``kernel``: None = band-sparse gather when the bank has that form, else the MFMA contraction ("mfma" forces it, as does
+        ``dense=True`` or SPECTRO_MEL_MFMA=1)."""
+        import os
+        if kernel is None:
+            kernel = "mfma" if (dense or self._sparse is None or os.environ.get("SPECTRO_MEL_MFMA") == "1") else "sparse"
+        if kernel == "sparse":
+            ipl, (b_start, b_w, b_first, b_count) = self._sparse
+            _capi.check(_capi.lib().sg_mel_sparse(C.c_void_p(spec_ptr), int(n_rows), self.n_bins, C.c_void_p(b_start.ptr), C.c_void_p(b_w.ptr),
+                                                  C.c_void_p(b_first.ptr), C.c_void_p(b_count.ptr), ipl, self.n_mels, int(bool(log_scale)),
+                                                  C.c_void_p(out_ptr), C.c_void_p(stream)))
+            return
         _capi.check(_capi.lib().sg_mel(C.c_void_p(spec_ptr), int(n_rows), self.n_bins, C.c_void_p(self._dev.ptr), self.n_mels,
                                        None if dense else self._k_lo, None if dense else self._k_hi, int(bool(log_scale)),
                                        C.c_void_p(out_ptr), C.c_void_p(stream)))
 
-    def apply(self, dev_spec, log_scale: bool = False, dense: bool = False):
+    def apply(self, dev_spec, log_scale: bool = False, dense: bool = False, kernel=None):
         """Mel spectrogram of a ``DeviceSpectrogram`` (f32) -> host array ``[..., n_mels, n_frames]``."""
         if dev_spec.dtype_code != _capi.F32 or dev_spec.n_bins != self.n_bins:
             raise ValueError("mel needs an f32 spectrum with nfft//2+1 bins of this bank")
@@ -72,7 +84,7 @@ class MelBank:
         if out.size:
             d = _capi.DeviceBuffer(out.nbytes)
             try:
-                self.apply_ptr(dev_spec.buf.ptr, dev_spec.rows, d.ptr, log_scale, dense)
+                self.apply_ptr(dev_spec.buf.ptr, dev_spec.rows, d.ptr, log_scale, dense, kernel=kernel)
                 d.download(out)
                 _capi.stream_sync()
             finally:

@@ -161,8 +161,8 @@ def test_mel_epilogue_vs_own_oracle():
     s = np.moveaxis(dev.to_host(), -1, -2)                    # [clip, frame, bin]
     for log in (False, True):
         ref = np.moveaxis(mel_oracle.mel_spectrogram(s, w.astype(np.float32), log), -1, -2)
-        for dense in (False, True):
-            got = bank.apply(dev, log_scale=log, dense=dense)
+        for dense, kernel in ((False, None), (False, "mfma"), (True, None)):      # band-sparse gather (default), block-sparse MFMA, dense MFMA
+            got = bank.apply(dev, log_scale=log, dense=dense, kernel=kernel)
             assert got.shape == ref.shape == (2, 80, dev.n_frames)
             if log:
                 assert np.abs(got - ref).max() < 1e-3          # dB
@@ -172,8 +172,9 @@ def test_mel_epilogue_vs_own_oracle():
     dev2 = engine.stft(x[0, :9000], fs=48000.0, nperseg=1024, window="hann", noverlap=512)
     bank2 = MelBank(1024, 48000.0, 37)
     ref2 = (np.moveaxis(dev2.to_host(), -1, -2).astype(np.float64) @ bank2.weights.astype(np.float32)).T
-    got2 = bank2.apply(dev2)
-    assert got2.shape == ref2.shape and np.allclose(got2, ref2, rtol=2e-5, atol=1e-6 * ref2.max())
+    for kernel in (None, "mfma"):
+        got2 = bank2.apply(dev2, kernel=kernel)
+        assert got2.shape == ref2.shape and np.allclose(got2, ref2, rtol=2e-5, atol=1e-6 * ref2.max())
     dev.free(); dev2.free(); bank.close(); bank2.close()
 
 
@@ -428,11 +429,12 @@ def test_mel_abi_shapes(nfft, n_mels, rows):
     d_in, d_out = _capi.DeviceBuffer(spec.nbytes), _capi.DeviceBuffer(rows * n_mels * 4)
     d_in.upload(spec)
     ref = spec.astype(np.float64) @ bank.weights.astype(np.float32).astype(np.float64)
-    for dense in (False, True):
+    variants = [(False, "mfma"), (True, None)] + ([(False, "sparse")] if bank._sparse is not None else [])
+    for dense, kernel in variants:
         got = np.zeros((rows, n_mels), np.float32)
-        bank.apply_ptr(d_in.ptr, rows, d_out.ptr, False, dense)
+        bank.apply_ptr(d_in.ptr, rows, d_out.ptr, False, dense, kernel=kernel)
         d_out.download(got); _capi.stream_sync()
-        assert np.allclose(got, ref, rtol=2e-5, atol=2e-6 * ref.max())
+        assert np.allclose(got, ref, rtol=2e-5, atol=2e-6 * ref.max()), (dense, kernel)
     d_in.free(); d_out.free(); bank.close()
 
 

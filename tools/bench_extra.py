@@ -51,7 +51,8 @@ bank = MelBank(1024, 48000.0, 80, 0.0, 24000.0)
 plan.stft(d_in.ptr, N, N, n_clips, d_spec.ptr, nfr * 513)
 frames = n_clips * nfr
 t_stft = timed(lambda: plan.stft(d_in.ptr, N, N, n_clips, d_spec.ptr, nfr * 513), iters=200, settle_s=0.5)
-t_mel = timed(lambda: bank.apply_ptr(d_spec.ptr, frames, d_mel.ptr, True), iters=200, settle_s=0.5)
+t_mel = timed(lambda: bank.apply_ptr(d_spec.ptr, frames, d_mel.ptr, True, kernel="mfma"), iters=200, settle_s=0.5)
+t_mel_sparse = timed(lambda: bank.apply_ptr(d_spec.ptr, frames, d_mel.ptr, True), iters=200, settle_s=0.5)
 t_mel_dense = timed(lambda: bank.apply_ptr(d_spec.ptr, frames, d_mel.ptr, True, dense=True), iters=100, settle_s=0.3)
 t_fused_mfma = timed(lambda: bank.stft_mel_ptr(plan, d_in.ptr, N, N, n_clips, d_mel.ptr, nfr * 80, True, kernel="mfma"), iters=200, settle_s=0.5)
 t_fused = timed(lambda: bank.stft_mel_ptr(plan, d_in.ptr, N, N, n_clips, d_mel.ptr, nfr * 80, True), iters=200, settle_s=0.5)
@@ -59,6 +60,7 @@ steps_sparse = sum((hi - lo) // 4 for lo, hi in bank.tile_ranges)
 flops_dense = 2.0 * 513 * 80 * frames
 res["cfg3_mel"] = {
     "frames": frames, "stft_us": t_stft * 1e6, "mel_us": t_mel * 1e6, "mel_dense_us": t_mel_dense * 1e6,
+    "mel_band_sparse_us": t_mel_sparse * 1e6, "mel_band_sparse_hbm_GBps": frames * (513 + 80) * 4 / t_mel_sparse / 1e9,
     "stft_plus_mel_frames_per_s": frames / (t_stft + t_mel),
     "fused_us": t_fused * 1e6, "fused_frames_per_s": frames / t_fused,
     "fused_kernel": "stft1024_r8x3_kernel OUT_MEL (band-sparse epilogue, %d work items per lane)" % (bank._sparse[0] if bank._sparse else 0),
