@@ -247,8 +247,8 @@ def band_features(x, fs, nperseg, fmin, fmax, window=("tukey", .25), noverlap=No
     n_frames = plan.n_frames(n_samples)
     if xh.size == 0 or n_frames == 0:
         return None, None
-    f = _capi.freqs(nfft, fs)
-    t = _capi.times(n_samples, nperseg, hop, fs)
+    from .signal import _freqs_times
+    f, t = _freqs_times(n_samples, nperseg, hop, nfft, fs)
     k_lo, k_hi = bin_range(f, fmin, fmax)
     dt = _np_dtype(code)
     if k_lo > k_hi:      # empty mask: np.sum over no rows = 0 -> log10(1e-20) = -20, diff 0 (PlotEngine.py:239-241)
@@ -258,6 +258,22 @@ def band_features(x, fs, nperseg, fmin, fmax, window=("tukey", .25), noverlap=No
     if use_i16:
         xh = xh.astype(dt)
     isz = np.dtype(dt).itemsize
+    from . import signal as _sig
+    if plan.kernel != "bluestein" and xh.nbytes + n_clips * n_frames * 2 * isz <= _sig._ZERO_COPY_MAX_BYTES:
+        # GUI-sized call (PlotEngine.py:232 on one sweep): the kernels read the samples from and write the features to pinned
+        # host memory directly -- no DMA transfers, one synchronisation (spectro.signal, zero-copy path)
+        s_in = _sig._pinned_bytes("in", xh.nbytes)
+        s_out = _sig._pinned_bytes("out", n_clips * n_frames * 2 * isz)
+        s_in[:xh.nbytes].view(xh.dtype).reshape(xh.shape)[...] = xh
+        band = _capi.DeviceBuffer(n_clips * n_frames * isz)
+        try:
+            plan.band_power(s_in.ctypes.data, n_samples, n_samples, n_clips, k_lo, k_hi, band.ptr, n_frames)
+            _capi.check(_capi.lib().sg_band_features_batch(C.c_void_p(band.ptr), code, n_clips, n_frames, C.c_void_p(s_out.ctypes.data), None))
+            _capi.stream_sync()
+            feats = s_out[:n_clips * n_frames * 2 * isz].view(dt).reshape(n_clips, n_frames, 2).copy()
+        finally:
+            band.free()
+        return t, feats.reshape(*outer, n_frames, 2)
     d_in = _capi.DeviceBuffer(xh.nbytes)
     band = _capi.DeviceBuffer(n_clips * n_frames * isz)
     try:

@@ -27,6 +27,51 @@ __all__ = ["spectrogram", "resolve_segments", "plan_for", "compute_dtype"]
 _MODES = ("psd", "complex", "magnitude", "angle", "phase")
 _plan_cache: "OrderedDict[tuple, _capi.Plan]" = OrderedDict()
 _PLAN_CACHE_MAX = 32
+_window_cache: "OrderedDict[tuple, np.ndarray]" = OrderedDict()      # (window spec, nperseg) -> read-only f64 table
+_ft_cache: "OrderedDict[tuple, tuple]" = OrderedDict()               # (n_samples, nperseg, hop, nfft, fs) -> (f, t), read-only
+_SMALL_CACHE_MAX = 64
+# GUI-sized calls (the reference's own use: one sweep, a few dozen frames) are dominated by the two DMA transfers and
+# their synchronisation, not by the kernel: below this many bytes of input + output the kernel reads the samples from, and
+# writes the spectrum to, PINNED HOST memory directly (zero-copy over PCIe) -- one launch and one synchronisation.
+_ZERO_COPY_MAX_BYTES = int(__import__("os").environ.get("SPECTRO_ZERO_COPY_BYTES", str(1 << 20)))
+_staging = {"in": None, "out": None}                                 # pinned numpy byte arrays, grown on demand
+
+
+def _cached_window(window, nperseg):
+    key = (window, int(nperseg))
+    w = _window_cache.get(key)
+    if w is None:
+        w = np.ascontiguousarray(get_window(window, nperseg), np.float64)
+        w.setflags(write=False)
+        _window_cache[key] = w
+        while len(_window_cache) > _SMALL_CACHE_MAX:
+            _window_cache.popitem(last=False)
+    else:
+        _window_cache.move_to_end(key)
+    return w
+
+
+def _freqs_times(n_samples, nperseg, hop, nfft, fs):
+    """A7 vectors (bit-exact with scipy, computed by the C side), cached per parameter set; callers get their own copies."""
+    key = (int(n_samples), int(nperseg), int(hop), int(nfft), float(fs))
+    ft = _ft_cache.get(key)
+    if ft is None:
+        ft = (_capi.freqs(nfft, fs), _capi.times(n_samples, nperseg, hop, fs))
+        _ft_cache[key] = ft
+        while len(_ft_cache) > _SMALL_CACHE_MAX:
+            _ft_cache.popitem(last=False)
+    else:
+        _ft_cache.move_to_end(key)
+    return ft[0].copy(), ft[1].copy()
+
+
+def _pinned_bytes(which, nbytes):
+    from .pipeline import pinned_empty
+    buf = _staging[which]
+    if buf is None or buf.nbytes < nbytes:
+        buf = pinned_empty((max(int(nbytes), 4096) * 2,), np.uint8)
+        _staging[which] = buf
+    return buf
 
 
 def resolve_segments(window, nperseg, input_length):
@@ -38,7 +83,10 @@ def resolve_segments(window, nperseg, input_length):
             warnings.warn(f"nperseg = {nperseg:d} is greater than input length "
                           f" = {input_length:d}, using nperseg = {input_length:d}", stacklevel=3)
             nperseg = input_length
-        win = get_window(window, nperseg)
+        try:
+            win = _cached_window(window, nperseg)
+        except TypeError:                                    # unhashable window spec: build it every time
+            win = get_window(window, nperseg)
     else:
         win = np.asarray(window)
         if len(win.shape) != 1:
@@ -132,24 +180,31 @@ def spectrogram(x, fs=1.0, window=("tukey", .25), nperseg=None, noverlap=None, n
     per_bin = 2 if mode == "complex" else 1
     out = np.empty((n_clips, n_frames, n_bins * per_bin), cdt)
 
-    d_in = _capi.DeviceBuffer(xh.nbytes)
-    d_out = _capi.DeviceBuffer(max(out.nbytes, 8))
-    try:
-        # (pinning the numpy buffers in place with sg_host_register was measured: 18-27 ms vs 23 ms for the cfg2
-        #  batch -- registration costs what it saves; callers that care keep data on the device via spectro.engine)
-        d_in.upload(xh)
-        plan.stft(d_in.ptr, n_samples, n_samples, n_clips, d_out.ptr, n_frames * n_bins * per_bin, int16=use_i16)
-        d_out.download(out)
+    if 0 < xh.nbytes + out.nbytes <= _ZERO_COPY_MAX_BYTES and out.size:
+        # zero-copy: the kernel's loads and stores cross PCIe themselves (cfg1: 44.9 -> ~27 us for the device part)
+        s_in, s_out = _pinned_bytes("in", xh.nbytes), _pinned_bytes("out", out.nbytes)
+        s_in[:xh.nbytes].view(xh.dtype).reshape(xh.shape)[...] = xh
+        plan.stft(s_in.ctypes.data, n_samples, n_samples, n_clips, s_out.ctypes.data, n_frames * n_bins * per_bin, int16=use_i16)
         _capi.stream_sync()
-    finally:
-        d_in.free()
-        d_out.free()
+        out[...] = s_out[:out.nbytes].view(out.dtype).reshape(out.shape)
+    else:
+        d_in = _capi.DeviceBuffer(xh.nbytes)
+        d_out = _capi.DeviceBuffer(max(out.nbytes, 8))
+        try:
+            # (pinning the numpy buffers in place with sg_host_register was measured: 18-27 ms vs 23 ms for the cfg2
+            #  batch -- registration costs what it saves; batch callers use spectro.pipeline or keep data on the device)
+            d_in.upload(xh)
+            plan.stft(d_in.ptr, n_samples, n_samples, n_clips, d_out.ptr, n_frames * n_bins * per_bin, int16=use_i16)
+            d_out.download(out)
+            _capi.stream_sync()
+        finally:
+            d_in.free()
+            d_out.free()
 
     if mode == "complex":
         out = out.view(np.complex64 if cdt == np.float32 else np.complex128)
     res = out.reshape(*outer, n_frames, n_bins)
-    f = _capi.freqs(nfft, fs)
-    t = _capi.times(n_samples, nperseg, hop, fs)
+    f, t = _freqs_times(n_samples, nperseg, hop, nfft, fs)
     ax = axis - 1 if axis < 0 else axis
     res = np.moveaxis(res, -1, ax)                     # frequency where the data axis was; time last
     if mode == "phase":

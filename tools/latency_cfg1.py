@@ -25,3 +25,16 @@ for name, (x, fs, n) in cases.items():
     g = bench(lambda: spectro.spectrogram(x, fs=fs, nperseg=n, scaling="density", mode="psd"))
     c = bench(lambda: sp_spectrogram(x, fs=fs, nperseg=n, scaling="density", mode="psd"), 50)
     print(f"{name:45s} device path {g[0]:8.1f} us (p99 {g[1]:8.1f})   scipy {c[0]:8.1f} us (p99 {c[1]:8.1f})")
+
+# the reference's second call site (PlotEngine.py:232): band features of one sweep
+from spectro import engine
+import scipy.signal as ss
+for name, (x, fs, n) in cases.items():
+    g = bench(lambda: engine.band_features(x, fs, n, 5.0, 30.0 if fs < 1000 else 3000.0))
+    def ref():
+        f, t, s = ss.spectrogram(x, fs=fs, nperseg=n, scaling="density", mode="psd")
+        m = (f >= 5.0) & (f <= (30.0 if fs < 1000 else 3000.0))
+        lp = np.log10(s[m].sum(axis=0) + 1e-20)
+        return np.column_stack([lp, np.diff(lp, prepend=lp[0])])
+    c = bench(ref, 50)
+    print(f"features: {name:35s} device path {g[0]:8.1f} us (p99 {g[1]:8.1f})   scipy+numpy {c[0]:8.1f} us (p99 {c[1]:8.1f})")
