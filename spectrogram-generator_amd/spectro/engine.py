@@ -262,15 +262,16 @@ def band_features(x, fs, nperseg, fmin, fmax, window=("tukey", .25), noverlap=No
     if plan.kernel != "bluestein" and xh.nbytes + n_clips * n_frames * 2 * isz <= _sig._ZERO_COPY_MAX_BYTES:
         # GUI-sized call (PlotEngine.py:232 on one sweep): the kernels read the samples from and write the features to pinned
         # host memory directly -- no DMA transfers, one synchronisation (spectro.signal, zero-copy path)
-        s_in = _sig._pinned_bytes("in", xh.nbytes)
-        s_out = _sig._pinned_bytes("out", n_clips * n_frames * 2 * isz)
-        s_in[:xh.nbytes].view(xh.dtype).reshape(xh.shape)[...] = xh
         band = _capi.DeviceBuffer(n_clips * n_frames * isz)
         try:
-            plan.band_power(s_in.ctypes.data, n_samples, n_samples, n_clips, k_lo, k_hi, band.ptr, n_frames)
-            _capi.check(_capi.lib().sg_band_features_batch(C.c_void_p(band.ptr), code, n_clips, n_frames, C.c_void_p(s_out.ctypes.data), None))
-            _capi.stream_sync()
-            feats = s_out[:n_clips * n_frames * 2 * isz].view(dt).reshape(n_clips, n_frames, 2).copy()
+            with _sig._staging_lock:
+                s_in = _sig._pinned_bytes("in", xh.nbytes)
+                s_out = _sig._pinned_bytes("out", n_clips * n_frames * 2 * isz)
+                s_in[:xh.nbytes].view(xh.dtype).reshape(xh.shape)[...] = xh
+                plan.band_power(s_in.ctypes.data, n_samples, n_samples, n_clips, k_lo, k_hi, band.ptr, n_frames)
+                _capi.check(_capi.lib().sg_band_features_batch(C.c_void_p(band.ptr), code, n_clips, n_frames, C.c_void_p(s_out.ctypes.data), None))
+                _capi.stream_sync()
+                feats = s_out[:n_clips * n_frames * 2 * isz].view(dt).reshape(n_clips, n_frames, 2).copy()
         finally:
             band.free()
         return t, feats.reshape(*outer, n_frames, 2)

@@ -35,6 +35,7 @@ _SMALL_CACHE_MAX = 64
 # writes the spectrum to, PINNED HOST memory directly (zero-copy over PCIe) -- one launch and one synchronisation.
 _ZERO_COPY_MAX_BYTES = int(__import__("os").environ.get("SPECTRO_ZERO_COPY_BYTES", str(1 << 20)))
 _staging = {"in": None, "out": None}                                 # pinned numpy byte arrays, grown on demand
+_staging_lock = __import__("threading").Lock()                       # one zero-copy call at a time owns the staging pair
 
 
 def _cached_window(window, nperseg):
@@ -182,11 +183,12 @@ def spectrogram(x, fs=1.0, window=("tukey", .25), nperseg=None, noverlap=None, n
 
     if 0 < xh.nbytes + out.nbytes <= _ZERO_COPY_MAX_BYTES and out.size:
         # zero-copy: the kernel's loads and stores cross PCIe themselves (cfg1: 44.9 -> ~27 us for the device part)
-        s_in, s_out = _pinned_bytes("in", xh.nbytes), _pinned_bytes("out", out.nbytes)
-        s_in[:xh.nbytes].view(xh.dtype).reshape(xh.shape)[...] = xh
-        plan.stft(s_in.ctypes.data, n_samples, n_samples, n_clips, s_out.ctypes.data, n_frames * n_bins * per_bin, int16=use_i16)
-        _capi.stream_sync()
-        out[...] = s_out[:out.nbytes].view(out.dtype).reshape(out.shape)
+        with _staging_lock:
+            s_in, s_out = _pinned_bytes("in", xh.nbytes), _pinned_bytes("out", out.nbytes)
+            s_in[:xh.nbytes].view(xh.dtype).reshape(xh.shape)[...] = xh
+            plan.stft(s_in.ctypes.data, n_samples, n_samples, n_clips, s_out.ctypes.data, n_frames * n_bins * per_bin, int16=use_i16)
+            _capi.stream_sync()
+            out[...] = s_out[:out.nbytes].view(out.dtype).reshape(out.shape)
     else:
         d_in = _capi.DeviceBuffer(xh.nbytes)
         d_out = _capi.DeviceBuffer(max(out.nbytes, 8))

@@ -267,6 +267,41 @@ def test_gui_range_large_nperseg(sp, nperseg, dtype):
     assert np.allclose(feats[:, 0], lp, atol=1e-9 if dtype == np.float64 else 2e-5)
 
 
+def test_concurrent_callers_share_the_staging_and_the_pools(sp):
+    """The library is re-entrant per (plan, stream) and the shim keeps process-wide caches (plans, windows, pinned staging for
+    the zero-copy path, device and pinned pools): eight threads hammering small and medium calls must all get their own,
+    correct results."""
+    import threading
+    rng = np.random.default_rng(99)
+    jobs = []
+    for i in range(8):
+        n = (256, 512, 1024, 100)[i % 4]
+        x = (rng.standard_normal(3000 + 997 * i) * (1 + i)).astype(np.float32 if i % 2 else np.float64)
+        jobs.append((x, dict(fs=1000.0 + i, nperseg=n)))
+    refs = [orc.spectrogram(x, **kw) for x, kw in jobs]
+    errors = []
+
+    def worker(idx):
+        try:
+            x, kw = jobs[idx]
+            for _ in range(40):
+                f, t, s = sp.spectrogram(x, **kw)
+                fo, to, so = refs[idx]
+                assert np.array_equal(f, fo) and np.array_equal(t, to) and s.shape == so.shape
+                if x.dtype == np.float64:
+                    assert np.abs(s - so).max() <= 1e-11 * np.abs(so).max()
+                else:
+                    assert_spec_close(s, so, time_axis=-1)
+        except Exception as e:                      # noqa: BLE001 - reported below
+            errors.append((idx, repr(e)))
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+
+
 def test_axis_argument(sp):
     rng = np.random.default_rng(8)
     x = rng.standard_normal((700, 3)).astype(np.float32)
