@@ -4,7 +4,7 @@
 // Same algorithm as the reference's call chain (scipy/signal/_spectral_py.py:2180-2202 and :2125-2134),
 // organised for a workgroup instead of a wavefront: a group of TPF threads owns one frame in LDS,
 //   load -> (sum x, sum u*x) -> detrend (none | constant | linear) -> window -> zero pad
-//   -> nfft/2-point complex Stockham radix-2 autosort FFT on the even/odd packed signal
+//   -> nfft/2-point complex Stockham autosort FFT (radix-4 passes + one radix-2 when needed) on the even/odd packed signal
 //   -> split pass -> |X|^2*scale (one-sided doubling) | |X| | X | arg X -> HBM.
 // Small transforms pack several frames into one 256-thread workgroup.  The r8x3 kernel
 // (stft_r8x3.hip) is the fast path for the headline size; this kernel is the correctness net for
@@ -40,7 +40,24 @@ struct GenParams {
     const Cx<T>* tw;          // [nfft/2]  exp(-2*pi*i*k/nfft)
     T scale;                  // psd scale (already sqrt'ed for the non-psd modes)
     int band_mode, k_lo, k_hi;
+    int tw_lds;               // 1: the twiddle table (nfft/2 complex) is staged in LDS once per workgroup
 };
+
+// Sum of `v` over the tpf threads of a frame group (tpf a power of two, groups aligned): xor butterflies inside a wavefront,
+// and for groups of 128 / 256 threads one trip through `red` (2 or 4 doubles per group).  Every thread gets the total.
+// One workgroup barrier in the wide case, none otherwise (the tree over LDS it replaces took log2(tpf) barriers).
+__device__ __forceinline__ double group_sum(double v, int tpf, int tid, double* red) {
+    const int w = tpf < 64 ? tpf : 64;
+    for (int o = w >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (tpf > 64) {
+        if ((tid & 63) == 0) red[tid >> 6] = v;
+        __syncthreads();
+        v = 0.0;
+        for (int i = 0; i < (tpf >> 6); ++i) v += red[i];
+        __syncthreads();                        // red is reused by the next reduction
+    }
+    return v;
+}
 
 template <typename T, typename TIn>
 __global__ __launch_bounds__(kThreads) void stft_stockham_kernel(const GenParams<T> p) {
@@ -56,7 +73,16 @@ __global__ __launch_bounds__(kThreads) void stft_stockham_kernel(const GenParams
     T* const base = reinterpret_cast<T*>(smem_raw);
     T* bufA = base + static_cast<size_t>(g) * 2 * buf_elems;
     T* bufB = bufA + buf_elems;
-    double* const red = reinterpret_cast<double*>(base + static_cast<size_t>(groups) * 2 * buf_elems) + static_cast<size_t>(g) * 2 * tpf;
+    double* const red_base = reinterpret_cast<double*>(base + static_cast<size_t>(groups) * 2 * buf_elems);
+    double* const red = red_base + static_cast<size_t>(g) * 2 * tpf;
+    // twiddles: staged in LDS once per workgroup when there is room (a stage's butterflies otherwise wait for L1 / L2)
+    const Cx<T>* twp = p.tw;
+    if (p.tw_lds) {
+        Cx<T>* const tw_l = reinterpret_cast<Cx<T>*>(red_base + static_cast<size_t>(groups) * 2 * tpf);
+        for (int i = threadIdx.x; i < M; i += kThreads) tw_l[i] = p.tw[i];
+        twp = tw_l;
+        __syncthreads();
+    }
 
     const int nbins = M + 1;
     const int n = p.nperseg;
@@ -77,27 +103,18 @@ __global__ __launch_bounds__(kThreads) void stft_stockham_kernel(const GenParams
                 if (i < n) {
                     v = static_cast<T>(src[i]);
                     s0 += static_cast<double>(v);
-                    s1 += static_cast<double>(v) * static_cast<double>(i + 1);
+                    if (p.detrend == SG_DETREND_LINEAR) s1 += static_cast<double>(v) * static_cast<double>(i + 1);
                 }
                 bufA[i] = v;
             }
         }
         T c0 = T(0), c1 = T(0);    // trend = c0 + c1 * (i+1)/n
         if (p.detrend != SG_DETREND_NONE) {
-            red[tid] = s0;
-            red[tpf + tid] = s1;
-            __syncthreads();
-            for (int s = tpf >> 1; s > 0; s >>= 1) {
-                if (tid < s) {
-                    red[tid] += red[tid + s];
-                    red[tpf + tid] += red[tpf + tid + s];
-                }
-                __syncthreads();
-            }
-            const double sx = red[0], sux = red[tpf] / n;     // u_i = (i+1)/n
+            const double sx = group_sum(s0, tpf, tid, red);
             if (p.detrend == SG_DETREND_CONSTANT) {
                 c0 = static_cast<T>(sx / n);
             } else {
+                const double sux = group_sum(s1, tpf, tid, red) / n;             // u_i = (i+1)/n
                 // least squares line through (u_i, x_i): x ~ beta*u + alpha
                 const double dn = n;
                 const double su = (dn + 1.0) * 0.5;                              // sum u
@@ -108,9 +125,6 @@ __global__ __launch_bounds__(kThreads) void stft_stockham_kernel(const GenParams
                 c0 = static_cast<T>(alpha);
                 c1 = static_cast<T>(beta / dn);
             }
-            __syncthreads();     // red is reused by the next frame
-        } else {
-            __syncthreads();
         }
 
         // ---- detrend + window (A3, A4), in place; bufA viewed as M complex ----
@@ -122,17 +136,46 @@ __global__ __launch_bounds__(kThreads) void stft_stockham_kernel(const GenParams
         }
         __syncthreads();
 
-        // ---- M-point complex Stockham radix-2 FFT (A5) ------------------------
+        // ---- M-point complex Stockham autosort FFT (A5): radix-4 passes (two radix-2 stages per trip through LDS and per
+        //      barrier), one radix-2 pass at the end when log2(M) is odd ---------------------------------------------------
         Cx<T>* src_c = reinterpret_cast<Cx<T>*>(bufA);
         Cx<T>* dst_c = reinterpret_cast<Cx<T>*>(bufB);
-        const int half = M >> 1;
-        for (int st = 0; st < p.log2m; ++st) {
+        const int half = M >> 1, quarter = M >> 2;
+        int st = 0;
+        for (; st + 1 < p.log2m; st += 2) {
+            const int pp = 1 << st;
+            if (active) {
+                for (int i = tid; i < quarter; i += tpf) {
+                    const int k = i & (pp - 1);
+                    const int j = ((i - k) << 2) + k;
+                    // w1 = exp(-2*pi*i*k/(4pp)) = tw[k * M/(2pp)], w2 = w1^2, w3 = w1^3 (index past the half table: negated)
+                    const size_t i1 = static_cast<size_t>(k) * (M >> (st + 1));
+                    const Cx<T> w1 = twp[i1], w2 = twp[2 * i1];
+                    Cx<T> w3;
+                    if (3 * i1 < static_cast<size_t>(M)) { w3 = twp[3 * i1]; }
+                    else { const Cx<T> t = twp[3 * i1 - M]; w3 = {-t.x, -t.y}; }
+                    const Cx<T> a0 = src_c[i], a1 = src_c[i + quarter], a2 = src_c[i + half], a3 = src_c[i + half + quarter];
+                    const Cx<T> b1 = {a1.x * w1.x - a1.y * w1.y, a1.x * w1.y + a1.y * w1.x};
+                    const Cx<T> b2 = {a2.x * w2.x - a2.y * w2.y, a2.x * w2.y + a2.y * w2.x};
+                    const Cx<T> b3 = {a3.x * w3.x - a3.y * w3.y, a3.x * w3.y + a3.y * w3.x};
+                    const Cx<T> s02 = {a0.x + b2.x, a0.y + b2.y}, d02 = {a0.x - b2.x, a0.y - b2.y};
+                    const Cx<T> s13 = {b1.x + b3.x, b1.y + b3.y}, d13 = {b1.x - b3.x, b1.y - b3.y};
+                    dst_c[j] = {s02.x + s13.x, s02.y + s13.y};
+                    dst_c[j + pp] = {d02.x + d13.y, d02.y - d13.x};              // a0 - i b1 - b2 + i b3
+                    dst_c[j + 2 * pp] = {s02.x - s13.x, s02.y - s13.y};
+                    dst_c[j + 3 * pp] = {d02.x - d13.y, d02.y + d13.x};          // a0 + i b1 - b2 - i b3
+                }
+            }
+            __syncthreads();
+            Cx<T>* t = src_c; src_c = dst_c; dst_c = t;
+        }
+        if (st < p.log2m) {
             const int pp = 1 << st;
             if (active) {
                 for (int i = tid; i < half; i += tpf) {
                     const int k = i & (pp - 1);
                     const int j = ((i - k) << 1) + k;
-                    const Cx<T> w = p.tw[static_cast<size_t>(k) * (M >> st)];   // exp(-i*pi*k/pp)
+                    const Cx<T> w = twp[static_cast<size_t>(k) * (M >> st)];   // exp(-i*pi*k/pp)
                     const Cx<T> u0 = src_c[i];
                     const Cx<T> v = src_c[i + half];
                     const Cx<T> u1 = {v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x};
@@ -156,7 +199,7 @@ __global__ __launch_bounds__(kThreads) void stft_stockham_kernel(const GenParams
                 const T sx = A.x + Bz.x, sy = A.y - Bz.y;      // A + conj(B)
                 const T dx = A.x - Bz.x, dy = A.y + Bz.y;      // A - conj(B)
                 Cx<T> w;
-                if (k == M) { w.x = T(-1); w.y = T(0); } else { w = p.tw[k]; }
+                if (k == M) { w.x = T(-1); w.y = T(0); } else { w = twp[k]; }
                 // X = (S - i*W*D)/2 ; i*W*D = i*(wx*dx - wy*dy + i*(wx*dy + wy*dx))
                 const T tx = -(w.x * dy + w.y * dx), ty = w.x * dx - w.y * dy;
                 const T xr = T(0.5) * (sx - tx), xi = T(0.5) * (sy - ty);
@@ -179,13 +222,8 @@ __global__ __launch_bounds__(kThreads) void stft_stockham_kernel(const GenParams
             }
         }
         if (p.band_mode) {
-            red[tid] = bsum;
-            __syncthreads();
-            for (int s = tpf >> 1; s > 0; s >>= 1) {
-                if (tid < s) red[tid] += red[tid + s];
-                __syncthreads();
-            }
-            if (active && tid == 0) p.out[clip * p.out_clip_stride + f] = static_cast<T>(red[0]);
+            const double tot = group_sum(bsum, tpf, tid, red);
+            if (active && tid == 0) p.out[clip * p.out_clip_stride + f] = static_cast<T>(tot);
         }
         __syncthreads();     // buffers are rewritten by the next frame
     }
@@ -221,7 +259,11 @@ int launch_t(const sg_plan& p, const StftArgs& a) {
     prm.k_hi = a.k_hi;
 
     const int groups = kThreads / tpf;
-    const size_t lds = static_cast<size_t>(groups) * (2 * static_cast<size_t>(p.nfft) * sizeof(T) + 2 * tpf * sizeof(double));
+    size_t lds = static_cast<size_t>(groups) * (2 * static_cast<size_t>(p.nfft) * sizeof(T) + 2 * tpf * sizeof(double));
+    const size_t tw_bytes = static_cast<size_t>(M) * 2 * sizeof(T);
+    // only when the table costs no workgroup per CU (f64 nfft 4096: 64 + 32 KiB would drop from 2 to 1 and measured 0.72x)
+    prm.tw_lds = (lds + tw_bytes <= 160 * 1024 && (160 * 1024) / (lds + tw_bytes) == (160 * 1024) / lds) ? 1 : 0;
+    if (prm.tw_lds) lds += tw_bytes;
     if (lds > 160 * 1024) {
         set_error("stockham: nfft=%d in %s needs %zu B of LDS (> 160 KiB)", p.nfft, sizeof(T) == 8 ? "f64" : "f32", lds);
         return SG_ERR_UNSUPPORTED;
