@@ -13,12 +13,14 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 bad = 0
 fam = {}
 for it in range(cases):
-    nper = int(rng.choice([64, 128, 256, 256, 512, 512, 1024, 1024, 2048, 2048, 4096, 4096, 1000, 384]))
+    nper = int(rng.choice([64, 128, 256, 256, 512, 512, 1024, 1024, 2048, 2048, 4096, 4096, 1000, 384, 6000]))      # 6000: chirp-z, f64 in the HBM workspace
     r = rng.random()
     hop = int(rng.choice([64, 128, 256, 512])) if r < 0.5 else (nper - nper // 8 if r < 0.7 else int(rng.integers(1, nper + 1)))
     hop = max(1, min(hop, nper))
     n_clips = int(rng.choice([1, 2, 3, 7, 16, 33, 70]))
     n_frames = int(rng.choice([1, 2, 3, 5, 17, 64, 131, 400]))
+    if nper == 6000:
+        n_clips, n_frames = min(n_clips, 3), min(n_frames, 5)
     N = nper + hop * (n_frames - 1) + int(rng.integers(0, hop))
     mode = str(rng.choice(["psd", "psd", "psd", "magnitude", "complex", "angle"]))
     scaling = str(rng.choice(["density", "spectrum"]))
@@ -56,4 +58,51 @@ for it in range(cases):
         bad += 1
         print("FAIL", it, dict(n_clips=n_clips, N=N, dt=str(dt), **kw))
 print(f"{cases - bad}/{cases} cases agree with the oracle")
-sys.exit(1 if bad else 0)
+
+# ---- fused products of the nfft-1024 register kernel: band features, log display, mel ----
+from spectro import engine, _capi
+from spectro.mel import MelBank
+from oracle import mel_oracle
+pbad, pcases = 0, max(cases // 5, 20)
+for it in range(pcases):
+    hop = int(rng.choice([64, 128, 256, 512, 896, 100, 255, 1024]))
+    n_clips = int(rng.choice([1, 2, 5, 16, 37]))
+    n_frames = int(rng.choice([1, 2, 7, 33, 150]))
+    N = 1024 + hop * (n_frames - 1) + int(rng.integers(0, hop))
+    N += N % 2
+    fs = float(rng.choice([16000.0, 48000.0]))
+    detrend = ["constant", False][int(rng.integers(0, 2))]
+    x = (rng.standard_normal((n_clips, N)) * rng.uniform(0.05, 2.0) + rng.uniform(-0.5, 0.5)).astype(np.float32)
+    fmin, fmax = sorted(rng.uniform(0, fs / 2, 2))
+    if fmax - fmin < 3 * fs / 1024:
+        fmin, fmax = 0.0, fs / 2
+    ok = True
+    try:
+        fo, to, so = orc.spectrogram(x, fs=fs, nperseg=1024, window="hann", noverlap=1024 - hop, detrend=detrend)
+        m = (fo >= fmin) & (fo <= fmax)
+        dc = engine.DeviceClips(x)
+        t, feats = dc.band_log_power(fs, 1024, hop, fmin, fmax, window="hann", detrend=detrend)
+        lp = np.log10(so[:, m, :].sum(axis=1) + 1e-20)
+        ok &= np.array_equal(t, to) and bool(np.allclose(feats[..., 0], lp, atol=3e-5))
+        gmax = float(so.max()) * 1e8
+        fb, tt, img = dc.log_image(fs, 1024, hop, fmin, fmax, gmax, window="hann", detrend=detrend)
+        db = 10.0 * np.log10(np.clip(so[:, m, :] / (np.float32(gmax) + np.float32(1e-20)), 0, 1) + np.float32(1e-12))
+        ref = (db - db.min()) / (db.max() - db.min()) if db.max() - db.min() > 1e-6 else np.zeros_like(db)
+        ok &= img.shape == ref.shape and bool(np.abs(img - ref).max() <= 3e-3)
+        dc.free()
+        if hop % 2 == 0:
+            n_mels = int(rng.choice([8, 40, 80, 128]))
+            bank = MelBank(1024, fs, n_mels, 20.0, fs / 2 - 100.0)
+            plan = engine.plan_for(spectro.get_window("hann", 1024), 1024, 1024, hop, _capi.DETREND[detrend], fs, 0, 0, _capi.F32)
+            got = bank.stft_mel(x, plan, log_scale=False)
+            mref = np.moveaxis(mel_oracle.mel_spectrogram(np.moveaxis(so, -1, -2), bank.weights.astype(np.float32), False), -1, -2)
+            ok &= got.shape == mref.shape and bool(np.abs(got - mref).max() <= 1e-4 * mref.max())
+            bank.close()
+    except Exception as e:          # noqa: BLE001
+        ok = False
+        print("EXC", repr(e))
+    if not ok:
+        pbad += 1
+        print("PRODUCT FAIL", it, dict(n_clips=n_clips, N=N, hop=hop, fs=fs, detrend=detrend, band=(fmin, fmax)))
+print(f"{pcases - pbad}/{pcases} fused-product cases agree with the oracle")
+sys.exit(1 if (bad or pbad) else 0)
