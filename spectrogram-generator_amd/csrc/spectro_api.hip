@@ -24,6 +24,12 @@ static bool r8x3_ok(const sg_plan& p) {
            (p.mode == SG_MODE_PSD || p.mode == SG_MODE_MAGNITUDE);
 }
 
+static bool r8x3d_ok(const sg_plan& p) {
+    return p.dtype == SG_F64 && p.nperseg == 1024 && p.nfft == 1024 &&
+           (p.detrend == SG_DETREND_NONE || p.detrend == SG_DETREND_CONSTANT) &&
+           (p.mode == SG_MODE_PSD || p.mode == SG_MODE_MAGNITUDE);
+}
+
 static bool rsmall_ok(const sg_plan& p) {
     return p.dtype == SG_F32 && p.nperseg == p.nfft && (p.nfft == 256 || p.nfft == 512) &&
            (p.detrend == SG_DETREND_NONE || p.detrend == SG_DETREND_CONSTANT) &&
@@ -107,6 +113,7 @@ static int run_stft(const sg_plan* plan, StftArgs& a) {
     }
     switch (plan->kernel) {
         case Kernel::R8X3: return launch_r8x3(*plan, a);
+        case Kernel::R8X3D: return r8x3_f64_can_run(*plan, a) ? launch_r8x3_f64(*plan, a) : launch_stockham(*plan, a);
         case Kernel::RSMALL: return rsmall_can_run(*plan, a) ? launch_rsmall(*plan, a) : launch_stockham(*plan, a);
         case Kernel::RBIG: return rbig_can_run(*plan, a) ? launch_rbig(*plan, a) : launch_stockham(*plan, a);
         case Kernel::STOCKHAM: return launch_stockham(*plan, a);
@@ -239,6 +246,9 @@ int sg_plan_create(sg_plan** plan, int nperseg, int nfft, int hop, const double*
         if (r8x3_ok(*p)) {
             p->kernel = Kernel::R8X3;
             rc = build_r8x3_tables(*p, w);
+        } else if (r8x3d_ok(*p)) {
+            p->kernel = Kernel::R8X3D;
+            rc = build_r8x3_f64_tables(*p);
         } else if (rsmall_ok(*p)) {
             p->kernel = Kernel::RSMALL;
             rc = build_rsmall_tables(*p);
@@ -286,6 +296,7 @@ const char* sg_plan_kernel(const sg_plan* plan) {
     if (!plan) return "";
     switch (plan->kernel) {
         case Kernel::R8X3: return "r8x3";
+        case Kernel::R8X3D: return "r8x3d";
         case Kernel::RSMALL: return "rsmall";
         case Kernel::RBIG: return "rbig";
         case Kernel::STOCKHAM: return "stockham";
@@ -300,6 +311,12 @@ int sg_plan_force_kernel(sg_plan* plan, const char* name) {
         if (!r8x3_ok(*plan)) { set_error("plan cannot run on r8x3"); return SG_ERR_UNSUPPORTED; }
         if (!plan->r8_tw_dev) { std::vector<double> none; if (int rc = build_r8x3_tables(*plan, none)) return rc; }
         plan->kernel = Kernel::R8X3;
+        return SG_OK;
+    }
+    if (!strcmp(name, "r8x3d")) {
+        if (!r8x3d_ok(*plan)) { set_error("plan cannot run on r8x3d"); return SG_ERR_UNSUPPORTED; }
+        if (!plan->r8_tw_dev) { if (int rc = build_r8x3_f64_tables(*plan)) return rc; }
+        plan->kernel = Kernel::R8X3D;
         return SG_OK;
     }
     if (!strcmp(name, "rsmall")) {

@@ -18,7 +18,7 @@ int hip_fail(hipError_t e, const char* what);   // records message, returns SG_E
         if (e__ != hipSuccess) return ::sg::hip_fail(e__, #call);      \
     } while (0)
 
-enum class Kernel { R8X3, RSMALL, RBIG, STOCKHAM, BLUESTEIN };
+enum class Kernel { R8X3, R8X3D, RSMALL, RBIG, STOCKHAM, BLUESTEIN };
 
 }  // namespace sg
 
@@ -34,7 +34,7 @@ struct sg_plan {
     // device tables
     void* win_dev = nullptr;     // nperseg reals of dtype
     void* tw_dev = nullptr;      // nfft/2 complex of dtype: exp(-2*pi*i*k/nfft), k < nfft/2
-    void* r8_tw_dev = nullptr;   // R8X3: [18][64], RSMALL: [(R-1)+11][64] float2 per-lane twiddles
+    void* r8_tw_dev = nullptr;   // R8X3: [18][64] (R8X3D: double2), RSMALL: [(R-1)+11][64] float2 per-lane twiddles
     // Bluestein tables (complex of dtype)
     int bs_len = 0;              // padded pow2 length L >= 2*nfft-1
     void* bs_chirp_dev = nullptr;   // b[n] = exp(-i*pi*n^2/nfft), n < nfft
@@ -59,6 +59,8 @@ struct StftArgs {
 };
 
 int launch_r8x3(const sg_plan& p, const StftArgs& a);
+int launch_r8x3_f64(const sg_plan& p, const StftArgs& a);
+bool r8x3_f64_can_run(const sg_plan& p, const StftArgs& a);
 int r8x3_grid_waves(const sg_plan& p, int64_t total_frames, bool mel = false);   // waves (= min/max partials of the dB variant) of a launch
 // epilogue.hip: per-(device, stream) scratch of 256 KiB for reduction partials; fold of n (min, max) float pairs into mm[2]
 void* reduction_scratch(hipStream_t s);
@@ -71,6 +73,7 @@ int launch_stockham(const sg_plan& p, const StftArgs& a);
 int launch_bluestein(const sg_plan& p, const StftArgs& a);
 
 int build_r8x3_tables(sg_plan& p, const std::vector<double>& window);
+int build_r8x3_f64_tables(sg_plan& p);
 int build_rsmall_tables(sg_plan& p);
 int build_rbig_tables(sg_plan& p);
 int build_bluestein_tables(sg_plan& p);

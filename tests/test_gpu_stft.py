@@ -111,6 +111,71 @@ def test_r8x3_int16_input(sp):
     assert_spec_close(s, so, time_axis=-1)
 
 
+@pytest.mark.parametrize("hop,window,detrend,mode", [(896, ("tukey", 0.25), "constant", "psd"), (256, "hann", "constant", "psd"),
+                                                     (2, "hann", False, "psd"), (1024, "boxcar", False, "magnitude"),
+                                                     (334, ("tukey", 0.25), "constant", "magnitude"),
+                                                     (255, "hann", "constant", "psd")])      # odd hop: falls back to the LDS kernel
+def test_r8x3_f64_variants(sp, hop, window, detrend, mode):
+    """The reference's default nperseg on its float64 recordings: the double-precision register kernel (stft_r8x3_f64.hip)."""
+    from spectro import _capi
+    from spectro.signal import plan_for
+    from spectro.windows import get_window
+    rng = np.random.default_rng(1000 + hop)
+    n = 1024 + hop * 41 + 6
+    x = rng.standard_normal((3, n)) * 0.4 + 1.5
+    kw = dict(fs=20000.0, nperseg=1024, window=window, noverlap=1024 - hop, detrend=detrend, mode=mode)
+    f, t, s = sp.spectrogram(x, **kw)
+    fo, to, so = orc.spectrogram(x, **kw)
+    np.testing.assert_array_equal(f, fo)
+    np.testing.assert_array_equal(t, to)
+    _check(s, so, np.float64)
+    plan = plan_for(get_window(window, 1024), 1024, 1024, hop, _capi.DETREND[detrend], 20000.0, 0, _capi.MODE[mode], _capi.F64)
+    assert plan.kernel == "r8x3d"
+    # single clips at odd sample offsets of one buffer (8-byte aligned only) still work: the plan falls back per call
+    _, _, s1 = sp.spectrogram(x[1, 1:], **kw)
+    _, _, so1 = orc.spectrogram(x[1, 1:], **kw)
+    _check(s1, so1, np.float64)
+
+
+def test_r8x3_f64_matches_stockham_and_edges(sp):
+    from spectro import _capi
+    from spectro.signal import plan_for
+    from spectro.windows import get_window
+    rng = np.random.default_rng(77)
+    ns = 1024 + 896 * 9                                     # 10 frames per clip, 7 clips: fewer frames than waves on the chip
+    x = rng.standard_normal((7, ns))
+    x[2] = 0.0                                              # all-zero clip
+    x[3] = 3.25                                             # constant clip: detrended to exact zeros
+    plan = plan_for(get_window(("tukey", 0.25), 1024), 1024, 1024, 896, 1, 20000.0, 0, 0, _capi.F64)
+    assert plan.kernel == "r8x3d"
+    nfr, nb = plan.n_frames(ns), 513
+    d_in, d_a, d_b = _capi.DeviceBuffer(x.nbytes), _capi.DeviceBuffer(7 * nfr * nb * 8), _capi.DeviceBuffer(7 * nfr * nb * 8)
+    d_in.upload(x)
+    plan.stft(d_in.ptr, ns, ns, 7, d_a.ptr, nfr * nb)
+    plan.force_kernel("stockham")
+    try:
+        plan.stft(d_in.ptr, ns, ns, 7, d_b.ptr, nfr * nb)
+    finally:
+        plan.force_kernel("r8x3d")
+    a, b = np.empty((7, nfr, nb)), np.empty((7, nfr, nb))
+    d_a.download(a)
+    d_b.download(b)
+    _capi.stream_sync()
+    _check(np.moveaxis(a, 1, 2), np.moveaxis(b, 1, 2), np.float64)
+    assert np.all(a[2] == 0.0) and np.all(a[3] == 0.0)
+    _, _, so = orc.spectrogram(x, fs=20000.0, nperseg=1024)
+    _check(np.moveaxis(a, 1, 2), so, np.float64)
+    # a clip that starts on an odd sample of the device buffer (8-byte aligned only): the call falls back to the LDS kernel
+    plan.stft(d_in.ptr + 8, ns - 1, ns, 1, d_b.ptr, nfr * nb)
+    b1 = np.empty((plan.n_frames(ns - 1), nb))
+    d_b.download(b1)
+    _capi.stream_sync()
+    _, _, so1 = orc.spectrogram(x[0, 1:], fs=20000.0, nperseg=1024)
+    _check(b1.T, so1, np.float64)
+    with pytest.raises(NotImplementedError):
+        plan_for(get_window("hann", 1024), 1024, 1024, 256, 1, 1.0, 0, 0, _capi.F32).force_kernel("r8x3d")
+
+
 def test_full_size_properties(sp):
     """BASELINE cfg2 at full size (64 x 480000): size-independent properties.
 
