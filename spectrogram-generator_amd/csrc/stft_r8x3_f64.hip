@@ -1,6 +1,6 @@
 // stft_r8x3_f64.hip -- the nperseg = nfft = 1024 register kernel in double precision.
 //
-// Why it exists: the reference's default nperseg is 1024 (GUI.py:212) and its recordings arrive as float64 (neo magnitudes,
+// Why it exists: the reference's default nperseg is 1024 (GUI.py:214) and its recordings arrive as float64 (neo magnitudes,
 // SweepManager.py:135-136), and scipy computes in the input's precision (scipy/signal/_spectral_py.py:1976-1981) -- a batch
 // of f64 sweeps at the reference's own default is exactly this plan.  Until round 2 it ran on the LDS Stockham kernel
 // (stft_stockham.hip: one 256-thread workgroup per frame, a barrier per pass, 0.10 G frames/s).
