@@ -164,3 +164,44 @@ def run_sharded(n_clips: int, compute: Callable[[int, int], "object"], reduce_ma
     if reduce_max:
         res = global_max(res)
     return (start, stop), res
+
+
+def frame_shards(n_samples: int, nperseg: int, hop: int, world: int):
+    """One very long clip cut at frame boundaries: rank r owns frames ``[f_lo, f_hi)`` and reads samples
+    ``[f_lo*hop, (f_hi-1)*hop + nperseg)`` -- neighbours both read the ``nperseg - hop`` samples around a cut (a halo
+    READ of the caller's array, nothing is exchanged).  -> list of (f_lo, f_hi, s_lo, s_hi), one per rank."""
+    total = n_frames(n_samples, nperseg, hop)
+    out = []
+    for r in range(world):
+        lo, hi = shard_range(total, world, r)
+        out.append((lo, hi, lo * hop, (hi - 1) * hop + nperseg) if hi > lo else (lo, lo, lo * hop, lo * hop))
+    return out
+
+
+def long_clip_spectrogram(x, fs=1.0, window=("tukey", .25), nperseg=None, noverlap=None, nfft=None, detrend="constant",
+                          scaling="density", mode="psd", world=None, rank=None):
+    """This rank's share of ``spectrogram(x, ...)`` for one long 1-D recording that every rank can read (a memory-mapped
+    file, say): ``(f, t[f_lo:f_hi], Sxx[:, f_lo:f_hi], (f_lo, f_hi))``.  The shares of all ranks, concatenated along time,
+    are the single-process result bit for bit: the frames are the same frames run by the same plan, and ``t`` is a slice of
+    the full vector (A7), not recomputed from the shard."""
+    from . import _capi
+    from .signal import resolve_segments, spectrogram
+    if getattr(x, "ndim", None) != 1:                          # ndarray or np.memmap: only this rank's samples are touched
+        raise ValueError("long_clip_spectrogram takes one 1-D recording")
+    if mode == "phase":
+        raise ValueError("mode 'phase' unwraps along the whole time axis and cannot be cut into shards")
+    if world is None or rank is None:
+        world, rank = world_info()
+    win, nps = resolve_segments(window, nperseg, input_length=x.shape[-1])
+    nov = nps // 8 if noverlap is None else int(noverlap)
+    if nov >= nps:
+        raise ValueError("noverlap must be less than nperseg.")
+    hop = nps - nov
+    f_lo, f_hi, s_lo, s_hi = frame_shards(x.shape[0], nps, hop, world)[rank]
+    t_all = _capi.times(x.shape[0], nps, hop, fs)
+    if f_hi == f_lo:                                          # more ranks than frames
+        f, _, s = spectrogram(x[:nps], fs, win, nps, nov, nfft, detrend, scaling=scaling, mode=mode)
+        return f, t_all[:0], s[..., :0], (f_lo, f_hi)
+    f, _, s = spectrogram(x[s_lo:s_hi], fs, win, nps, nov, nfft, detrend, scaling=scaling, mode=mode)
+    assert s.shape[-1] == f_hi - f_lo
+    return f, t_all[f_lo:f_hi], s, (f_lo, f_hi)

@@ -174,17 +174,21 @@ def stft_pipelined(x, fs=1.0, window=("tukey", .25), nperseg=None, noverlap=None
         with _ws_lock:                                        # one pipelined call at a time shares the workspace
             streams, d_in, d_out = _ws.get(per_chunk * in_clip_bytes, per_chunk * row * out.dtype.itemsize)
             n_streams = 2 if n_clips > per_chunk else 1
-            for i, c0 in enumerate(range(0, n_clips, per_chunk)):
-                c1 = min(c0 + per_chunk, n_clips)
-                k = i % n_streams
-                s = streams[k]
-                # same stream => chunk i+2's upload queues behind chunk i's download: the buffers are safe to reuse
-                _capi.check(L.sg_memcpy_h2d(C.c_void_p(d_in[k].ptr), xh[c0:c1].ctypes.data_as(C.c_void_p),
-                                            (c1 - c0) * in_clip_bytes, s))
-                plan.stft(d_in[k].ptr, n_samples, n_samples, c1 - c0, d_out[k].ptr, row, stream=s.value, int16=use_i16)
-                _capi.check(L.sg_memcpy_d2h(out[c0:c1].ctypes.data_as(C.c_void_p), C.c_void_p(d_out[k].ptr),
-                                            (c1 - c0) * row * out.dtype.itemsize, s))
-            for s in streams[:n_streams]:
-                _capi.check(L.sg_stream_sync(s))
+            try:
+                for i, c0 in enumerate(range(0, n_clips, per_chunk)):
+                    c1 = min(c0 + per_chunk, n_clips)
+                    k = i % n_streams
+                    s = streams[k]
+                    # same stream => chunk i+2's upload queues behind chunk i's download: the buffers are safe to reuse
+                    _capi.check(L.sg_memcpy_h2d(C.c_void_p(d_in[k].ptr), xh[c0:c1].ctypes.data_as(C.c_void_p),
+                                                (c1 - c0) * in_clip_bytes, s))
+                    plan.stft(d_in[k].ptr, n_samples, n_samples, c1 - c0, d_out[k].ptr, row, stream=s.value, int16=use_i16)
+                    _capi.check(L.sg_memcpy_d2h(out[c0:c1].ctypes.data_as(C.c_void_p), C.c_void_p(d_out[k].ptr),
+                                                (c1 - c0) * row * out.dtype.itemsize, s))
+            finally:
+                # also on an error half way: no DMA may still be writing into `out` when its pinned block goes back to the pool
+                rcs = [L.sg_stream_sync(s) for s in streams[:n_streams]]
+            for rc in rcs:
+                _capi.check(rc)
     res = out.view(np.complex64 if cdt == np.float32 else np.complex128) if mode == "complex" else out
     return f, t, np.moveaxis(res.reshape(n_clips, n_frames, n_bins), -1, -2)

@@ -513,3 +513,29 @@ def test_sweepmanager_batch_pipeline_flag():
         fo, to, so = orc.spectrogram(np.stack([sm.data[k]["raw"] for k in names]), fs=8000.0, nperseg=n, window="hann", noverlap=n - h)
         np.testing.assert_array_equal(t, to)
         assert_spec_close(s, so, time_axis=-1)
+
+
+def test_long_clip_cut_at_frame_boundaries_is_the_whole_call():
+    """one long recording sharded over ranks by frames (halo read, no exchange): the ranks' shares concatenated
+    along time are the single-process result bit for bit, t included."""
+    import spectro
+    from spectro.dist import long_clip_spectrogram
+    rng = np.random.default_rng(99)
+    for dt, kw in [(np.float32, dict(nperseg=1024, window="hann", noverlap=768)), (np.float64, dict(nperseg=1024)),
+                   (np.float32, dict(nperseg=2048, window="hann", noverlap=1984)), (np.float64, dict(nperseg=500, noverlap=123)),
+                   (np.float32, dict(nperseg=512, mode="magnitude", detrend=False))]:
+        x = (rng.standard_normal(700001) * 0.2 + 0.1).astype(dt)
+        f, t, s = spectro.spectrogram(x, fs=48000.0, **kw)
+        for world in (3, 8):
+            parts = [long_clip_spectrogram(x, fs=48000.0, world=world, rank=r, **kw) for r in range(world)]
+            assert [p[3] for p in parts][0][0] == 0 and parts[-1][3][1] == t.size
+            np.testing.assert_array_equal(np.concatenate([p[1] for p in parts]), t)
+            np.testing.assert_array_equal(np.concatenate([p[2] for p in parts], axis=-1), s)
+            for p in parts:
+                np.testing.assert_array_equal(p[0], f)
+    # more ranks than frames: the extra ranks return empty shares
+    x = rng.standard_normal(1024 + 3 * 896).astype(np.float32)
+    parts = [long_clip_spectrogram(x, fs=1000.0, nperseg=1024, world=6, rank=r) for r in range(6)]
+    assert [p[2].shape[-1] for p in parts] == [1, 1, 1, 1, 0, 0]
+    with pytest.raises(ValueError):
+        long_clip_spectrogram(x, nperseg=1024, mode="phase", world=2, rank=0)

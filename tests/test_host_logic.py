@@ -247,6 +247,27 @@ def test_shard_arithmetic():
     assert max(loads) / (sum(loads) / 8) < 1.15
 
 
+def test_frame_shards_of_one_long_clip():
+    """a single long recording is cut at frame boundaries; every frame has one owner and an owner's sample range
+    holds exactly its frames (the halo of nperseg - hop samples is read by both neighbours)."""
+    from spectro.dist import frame_shards, n_frames
+    for n_samples, nperseg, hop in [(480000, 1024, 256), (30000, 256, 224), (1024, 1024, 1), (1023, 1024, 7), (5000, 1000, 999),
+                                    (100000, 4096, 64)]:
+        total = n_frames(n_samples, nperseg, hop)
+        for world in (1, 2, 3, 8, 50):
+            sh = frame_shards(n_samples, nperseg, hop, world)
+            assert len(sh) == world and sh[0][0] == 0 and sh[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(sh, sh[1:]))
+            for f_lo, f_hi, s_lo, s_hi in sh:
+                assert 0 <= s_lo <= s_hi <= n_samples
+                assert n_frames(s_hi - s_lo, nperseg, hop) == f_hi - f_lo
+                if f_hi > f_lo:
+                    assert s_lo == f_lo * hop and s_hi == (f_hi - 1) * hop + nperseg
+            for a, b in zip(sh, sh[1:]):
+                if a[1] > a[0] and b[1] > b[0]:
+                    assert a[3] - b[2] == nperseg - hop          # the halo both neighbours read
+
+
 GLOO_SCRIPT = textwrap.dedent('''
     import os, sys
     sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
