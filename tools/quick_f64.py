@@ -12,7 +12,10 @@ hop = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 secs = float(os.environ.get("QB_SECS", "1.0"))
 N = 480000
 _capi.ensure_device()
-for dt, code, isz, force in ((np.float64, _capi.F64, 8, None), (np.float64, _capi.F64, 8, "stockham"), (np.float32, _capi.F32, 4, None)):
+legs = ((np.float64, _capi.F64, 8, None), (np.float64, _capi.F64, 8, "stockham"), (np.float32, _capi.F32, 4, None))
+if os.environ.get("QF_LEGS"):                                # e.g. QF_LEGS=0 under tools/telemetry.py
+    legs = [legs[int(i)] for i in os.environ["QF_LEGS"].split(",")]
+for dt, code, isz, force in legs:
     x = (np.random.default_rng(1).standard_normal((n_clips, N)) * 0.1).astype(dt)
     plan = _capi.Plan(n, n, hop, get_window(("tukey", 0.25), n), 1, 48000.0, 0, 0, code)
     if force:
