@@ -13,8 +13,9 @@
 //     (tools/sim_r8x3.py) instead of a new analysis for 16-byte accesses;
 //   * 8 values + 8 prefetched + 16 window + 36 twiddle doubles per lane: ~230 VGPRs, two waves per SIMD;
 //   * no register sliding window (every frame reloads its 1024 samples from L1 / L2; the next frame's loads are issued before
-//     this frame's FFT) and only the PSD / magnitude rows: the fused products of the f32 kernel are not replicated here.
-// Algorithmic HBM bytes per frame: hop*8 + 513*8.
+//     this frame's FFT); of the fused products of the f32 kernel only the band power (A11: the HMM feature path on f64
+//     recordings, `sg_stft_band_power`) is replicated here.
+// Algorithmic HBM bytes per frame: hop*8 + 513*8 (band power: hop*8 + 8).
 #include "spectro_internal.h"
 
 #include <cmath>
@@ -90,9 +91,10 @@ struct R8DParams {
     const double2* win2;     // [512]  (w[2n], w[2n+1])
     const double2* tw;       // [18][64]: t1[r-1][j] = exp(-2 pi i j r/512), t2[s-1][j] = exp(-2 pi i (j&7) s/64), t3[m][j] = (cos, sin)(2 pi (j+64m)/1024)
     double scale;
+    int k_lo, k_hi;          // MODE 2: bins of the band
 };
 
-template <bool DETREND, int MODE>    // MODE 0 psd, 1 magnitude
+template <bool DETREND, int MODE>    // MODE 0 psd, 1 magnitude, 2 band power: out[clip][frame] = sum of PSD bins [k_lo, k_hi] (A11)
 __global__ __launch_bounds__(64 * kWaves, kOcc) void stft1024_r8x3_f64_kernel(const R8DParams p) {
     __shared__ __attribute__((aligned(16))) double lds[kWaves * 2 * kSlab];
     const int lane = threadIdx.x & 63;
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(64 * kWaves, kOcc) void stft1024_r8x3_f64_kernel(co
     if (lw >= p.n_waves) return;
 
     cd w[8], t1[7], t2[7], t3[4];
-    const double sq = sqrt(MODE == 0 ? p.scale * 0.5 : p.scale * 0.25);      // PSD scale rides on the window (stft_r8x3.hip)
+    const double sq = sqrt(MODE != 1 ? p.scale * 0.5 : p.scale * 0.25);      // PSD scale rides on the window (stft_r8x3.hip)
 #pragma unroll
     for (int a = 0; a < 8; ++a) { const double2 v = p.win2[lane + 64 * a]; w[a] = {v.x * sq, v.y * sq}; }
 #pragma unroll
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(64 * kWaves, kOcc) void stft1024_r8x3_f64_kernel(co
     }
 #pragma unroll
     for (int m = 0; m < 4; ++m) { const double2 v = p.tw[(14 + m) * 64 + lane]; t3[m] = {v.x, v.y}; }
-    const double r0 = (MODE == 0 && lane == 0) ? 0.5 : 1.0;
+    const double r0 = (MODE != 1 && lane == 0) ? 0.5 : 1.0;
 
     const int j0 = lane & 7, hi = lane >> 3;
     const int x1w = hi * kS1 + j0, x1r = lane, x2w = j0 * kS2 + hi, x2r = lane, x3w = lane, x3b = kM - lane;
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(64 * kWaves, kOcc) void stft1024_r8x3_f64_kernel(co
         const int f1 = static_cast<int>(min(static_cast<int64_t>(p.n_frames), f0 + (g_end - g)));
         g += f1 - f0;
         const double* src = p.x + static_cast<int64_t>(clip) * p.clip_stride + 2 * lane + static_cast<int64_t>(f0) * p.hop;
-        double* orow = p.out + static_cast<int64_t>(clip) * p.out_clip_stride + static_cast<int64_t>(f0) * kBins;
+        double* orow = p.out + static_cast<int64_t>(clip) * p.out_clip_stride + static_cast<int64_t>(f0) * (MODE == 2 ? 1 : kBins);
 
         cd raw[8];
 #pragma unroll
@@ -180,6 +182,7 @@ __global__ __launch_bounds__(64 * kWaves, kOcc) void stft1024_r8x3_f64_kernel(co
             sl.put(kM + lane, a[0]);                              // lane 0: Z[512] := Z[0]
             wave_lds_fence();
             // ---- split pass + |X|^2 (A5 tail, A6) ----
+            double bsum = 0.0;
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const cd A = a[m];
@@ -190,27 +193,39 @@ __global__ __launch_bounds__(64 * kWaves, kOcc) void stft1024_r8x3_f64_kernel(co
                 const cd T = {fma(cs.y, D.x, -cs.x * D.y), fma(cs.x, D.x, cs.y * D.y)};
                 const cd Xk = csub(S, T), Xm = cadd(S, T);
                 double pk = fma(Xk.x, Xk.x, Xk.y * Xk.y), pm = fma(Xm.x, Xm.x, Xm.y * Xm.y);
-                if (MODE == 0 && m == 0) { pk *= r0; pm *= r0; }
+                if (MODE != 1 && m == 0) { pk *= r0; pm *= r0; }
                 if (MODE == 1) { pk = sqrt(pk); pm = sqrt(pm); }
                 const int k = lane + 64 * m;
-                orow[k] = pk;
-                orow[kM - k] = pm;
+                if (MODE == 2) {
+                    if (k >= p.k_lo && k <= p.k_hi) bsum += pk;
+                    if (kM - k >= p.k_lo && kM - k <= p.k_hi) bsum += pm;
+                } else {
+                    orow[k] = pk;
+                    orow[kM - k] = pm;
+                }
             }
             {
                 const double zx = __shfl(a[4].x, 0), zy = __shfl(a[4].y, 0);     // k = 256 pairs with itself: lane 0's a[4]
                 double pq = fma(zx, zx, zy * zy) * 4.0;
                 if (MODE == 1) pq = sqrt(pq);
-                orow[256] = pq;
+                if (MODE == 2) {
+                    if (lane == 0 && 256 >= p.k_lo && 256 <= p.k_hi) bsum += pq;
+                    bsum = wave_sum(bsum);
+                    if (lane == 0) orow[0] = bsum;
+                } else {
+                    orow[256] = pq;
+                }
             }
-            orow += kBins;
+            orow += MODE == 2 ? 1 : kBins;
             wave_lds_fence();
         }
     }
 }
 
 template <bool DETREND>
-int launch_mode(const R8DParams& prm, int n_wg, hipStream_t s, int mode) {
-    if (mode == SG_MODE_PSD) hipLaunchKernelGGL((stft1024_r8x3_f64_kernel<DETREND, 0>), dim3(n_wg), dim3(64 * kWaves), 0, s, prm);
+int launch_mode(const R8DParams& prm, int n_wg, hipStream_t s, int mode, bool band) {
+    if (band) hipLaunchKernelGGL((stft1024_r8x3_f64_kernel<DETREND, 2>), dim3(n_wg), dim3(64 * kWaves), 0, s, prm);
+    else if (mode == SG_MODE_PSD) hipLaunchKernelGGL((stft1024_r8x3_f64_kernel<DETREND, 0>), dim3(n_wg), dim3(64 * kWaves), 0, s, prm);
     else hipLaunchKernelGGL((stft1024_r8x3_f64_kernel<DETREND, 1>), dim3(n_wg), dim3(64 * kWaves), 0, s, prm);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? SG_OK : hip_fail(e, "stft1024_r8x3_f64 launch");
@@ -219,7 +234,7 @@ int launch_mode(const R8DParams& prm, int n_wg, hipStream_t s, int mode) {
 }  // namespace
 
 bool r8x3_f64_can_run(const sg_plan& p, const StftArgs& a) {
-    return p.dtype == SG_F64 && !a.in_i16 && !a.band_mode && !a.db_mode && a.mel_ipl == 0 && (p.hop % 2 == 0) &&
+    return p.dtype == SG_F64 && !a.in_i16 && !a.db_mode && a.mel_ipl == 0 && (p.hop % 2 == 0) &&
            (a.clip_stride % 2 == 0 || a.n_clips == 1) && (reinterpret_cast<uintptr_t>(a.x) % 16 == 0) && a.n_frames <= INT32_MAX;
 }
 
@@ -240,8 +255,10 @@ int launch_r8x3_f64(const sg_plan& p, const StftArgs& a) {
     prm.win2 = static_cast<const double2*>(p.win_dev);
     prm.tw = static_cast<const double2*>(p.r8_tw_dev);
     prm.scale = p.scale;
+    prm.k_lo = a.k_lo; prm.k_hi = a.k_hi;
     const int n_wg = static_cast<int>((n_waves + kWaves - 1) / kWaves);
-    return p.detrend == SG_DETREND_CONSTANT ? launch_mode<true>(prm, n_wg, a.stream, p.mode) : launch_mode<false>(prm, n_wg, a.stream, p.mode);
+    const bool band = a.band_mode != 0;                     // run_stft has checked: psd plan, 0 <= k_lo <= k_hi < 513
+    return p.detrend == SG_DETREND_CONSTANT ? launch_mode<true>(prm, n_wg, a.stream, p.mode, band) : launch_mode<false>(prm, n_wg, a.stream, p.mode, band);
 }
 
 // the [18][64] per-lane twiddle table of stft_r8x3.hip in double

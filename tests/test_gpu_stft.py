@@ -165,6 +165,15 @@ def test_r8x3_f64_matches_stockham_and_edges(sp):
     assert np.all(a[2] == 0.0) and np.all(a[3] == 0.0)
     _, _, so = orc.spectrogram(x, fs=20000.0, nperseg=1024)
     _check(np.moveaxis(a, 1, 2), so, np.float64)
+    # fused band power (A11) on the same kernel: per-frame sums of bins [k_lo, k_hi], the spectrum is never written
+    d_bp = _capi.DeviceBuffer(7 * nfr * 8)
+    for k_lo, k_hi in [(0, 512), (3, 40), (256, 256), (255, 257), (257, 300), (0, 0), (512, 512), (100, 511)]:
+        plan.band_power(d_in.ptr, ns, ns, 7, k_lo, k_hi, d_bp.ptr, nfr)
+        bp = np.empty((7, nfr))
+        d_bp.download(bp)
+        _capi.stream_sync()
+        ref_bp = a[:, :, k_lo:k_hi + 1].sum(-1)
+        assert np.all(np.abs(bp - ref_bp) <= 1e-12 * np.abs(a).max(axis=-1) * (k_hi - k_lo + 1) + 1e-300), (k_lo, k_hi)
     # a clip that starts on an odd sample of the device buffer (8-byte aligned only): the call falls back to the LDS kernel
     plan.stft(d_in.ptr + 8, ns - 1, ns, 1, d_b.ptr, nfr * nb)
     b1 = np.empty((plan.n_frames(ns - 1), nb))
