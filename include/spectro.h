@@ -116,7 +116,7 @@ int sg_plan_n_frames(const sg_plan* plan, int64_t n_samples, int64_t* n_frames);
 int sg_plan_n_bins(const sg_plan* plan, int* n_bins);
 /* the scale factor the kernels multiply |X|^2 with (as double) */
 int sg_plan_scale(const sg_plan* plan, double* scale);
-/* name of the kernel family the plan dispatches to: "r8x3", "r8x3d" (f64 nperseg = nfft = 1024), "rsmall", "rbig", "stockham", "bluestein" */
+/* name of the kernel family the plan dispatches to: "r8x3", "r8x3d" / "rsmalld" (f64 nperseg = nfft = 1024 / 256, 512), "rsmall", "rbig", "stockham", "bluestein" */
 const char* sg_plan_kernel(const sg_plan* plan);
 /* Tests / benchmarks: route the plan to another family that can run it ("stockham" for an
  * r8x3 plan).  SG_ERR_UNSUPPORTED if that family cannot run this plan. */

@@ -25,7 +25,7 @@ static bool r8x3_ok(const sg_plan& p) {
 }
 
 static bool r8x3d_ok(const sg_plan& p) {
-    return p.dtype == SG_F64 && p.nperseg == 1024 && p.nfft == 1024 &&
+    return p.dtype == SG_F64 && p.nperseg == p.nfft && (p.nfft == 256 || p.nfft == 512 || p.nfft == 1024) &&
            (p.detrend == SG_DETREND_NONE || p.detrend == SG_DETREND_CONSTANT) &&
            (p.mode == SG_MODE_PSD || p.mode == SG_MODE_MAGNITUDE);
 }
@@ -296,7 +296,7 @@ const char* sg_plan_kernel(const sg_plan* plan) {
     if (!plan) return "";
     switch (plan->kernel) {
         case Kernel::R8X3: return "r8x3";
-        case Kernel::R8X3D: return "r8x3d";
+        case Kernel::R8X3D: return plan->nfft == 1024 ? "r8x3d" : "rsmalld";
         case Kernel::RSMALL: return "rsmall";
         case Kernel::RBIG: return "rbig";
         case Kernel::STOCKHAM: return "stockham";
@@ -313,8 +313,8 @@ int sg_plan_force_kernel(sg_plan* plan, const char* name) {
         plan->kernel = Kernel::R8X3;
         return SG_OK;
     }
-    if (!strcmp(name, "r8x3d")) {
-        if (!r8x3d_ok(*plan)) { set_error("plan cannot run on r8x3d"); return SG_ERR_UNSUPPORTED; }
+    if (!strcmp(name, "r8x3d") || !strcmp(name, "rsmalld")) {
+        if (!r8x3d_ok(*plan) || (plan->nfft == 1024) != !strcmp(name, "r8x3d")) { set_error("plan cannot run on %s", name); return SG_ERR_UNSUPPORTED; }
         if (!plan->r8_tw_dev) { if (int rc = build_r8x3_f64_tables(*plan)) return rc; }
         plan->kernel = Kernel::R8X3D;
         return SG_OK;

@@ -1,21 +1,22 @@
-// stft_r8x3_f64.hip -- the nperseg = nfft = 1024 register kernel in double precision.
+// stft_r8x3_f64.hip -- the register kernels in double precision: nperseg = nfft = 1024 ("r8x3d"), 512 and 256 ("rsmalld").
 //
-// Why it exists: the reference's default nperseg is 1024 (GUI.py:214) and its recordings arrive as float64 (neo magnitudes,
-// SweepManager.py:135-136), and scipy computes in the input's precision (scipy/signal/_spectral_py.py:1976-1981) -- a batch
-// of f64 sweeps at the reference's own default is exactly this plan.  Until round 2 it ran on the LDS Stockham kernel
-// (stft_stockham.hip: one 256-thread workgroup per frame, a barrier per pass, 0.10 G frames/s).
+// Why they exist: the reference's default nperseg is 1024 (GUI.py:214, spin box 32...8192) and its recordings arrive as float64
+// (neo magnitudes, SweepManager.py:135-136), and scipy computes in the input's precision (scipy/signal/_spectral_py.py:1976-1981)
+// -- a batch of f64 sweeps at the reference's own settings is exactly these plans.  Until round 2 they ran on the LDS Stockham
+// kernel (stft_stockham.hip: a workgroup per frame, a barrier per pass, 0.10 G frames/s at 1024).
 //
-// Same machine mapping as stft_r8x3.hip (read that file for the index maps): one wavefront = one frame, 512 complex points of
-// the even/odd packed signal as 8 complex values per lane, three register radix-8 passes, two padded LDS transposes (strides
-// 72 / 66 elements), a split pass in which only the upper half crosses lanes, no s_barrier in the frame loop.  Differences:
+// Same machine mapping as stft_r8x3.hip / stft_rsmall.hip (read those files for the index maps): one wavefront carries G = 8/R
+// frames (R = nfft/128), 8 complex values per lane, pass 1 = G R-point DFTs, passes 2/3 = register radix-8, two padded LDS
+// transposes (strides 72 / 66 elements), a split pass in which only the upper half crosses lanes, no s_barrier in the loop.
+// Differences from the f32 kernels:
 //   * a complex double is 16 bytes: the slab is kept as separate real and imaginary planes of 8-byte elements, so every exchange
-//     is two ds_write_b64 / ds_read_b64 with the index maps of the f32 kernel -- conflict-free by the same argument
-//     (tools/sim_r8x3.py) instead of a new analysis for 16-byte accesses;
-//   * 8 values + 8 prefetched + 16 window + 36 twiddle doubles per lane: ~230 VGPRs, two waves per SIMD;
-//   * no register sliding window (every frame reloads its 1024 samples from L1 / L2; the next frame's loads are issued before
-//     this frame's FFT); of the fused products of the f32 kernel only the band power (A11: the HMM feature path on f64
-//     recordings, `sg_stft_band_power`) is replicated here.
-// Algorithmic HBM bytes per frame: hop*8 + 513*8 (band power: hop*8 + 8).
+//     is two ds_write_b64 / ds_read_b64 with the index maps of the f32 kernels -- conflict-free by the same argument
+//     (tools/sim_r8x3.py, sim_rsmall.py) instead of a new analysis for 16-byte accesses;
+//   * 8 values + 8 prefetched + window + twiddle doubles per lane: 208-233 VGPRs at R = 8, two waves per SIMD;
+//   * no register sliding window (every group reloads its samples from L1 / L2; the next group's loads are issued before this
+//     group's FFT); of the fused products of the f32 kernel only the band power (A11: the HMM feature path on f64 recordings,
+//     `sg_stft_band_power`) is replicated here.
+// Algorithmic HBM bytes per frame: hop*8 + (nfft/2+1)*8 (band power: hop*8 + 8).
 #include "spectro_internal.h"
 
 #include <cmath>
@@ -24,7 +25,6 @@
 namespace sg {
 namespace {
 
-constexpr int kN = 1024, kM = 512, kBins = 513;
 constexpr int kS1 = 72, kS2 = 66, kSlab = 8 * kS1;       // 576 elements per plane
 constexpr int kWaves = 4;                                // per workgroup
 constexpr int kOcc = 2;                                  // waves per SIMD
@@ -84,18 +84,43 @@ struct R8DParams {
     const double* x;
     int64_t clip_stride;
     int n_frames, hop;
-    int64_t total_frames;
+    int groups_per_clip;     // ceil(n_frames / G), G = 8/R frames per wave step
+    int64_t total_groups;
     int n_waves;
     double* out;
     int64_t out_clip_stride;
-    const double2* win2;     // [512]  (w[2n], w[2n+1])
-    const double2* tw;       // [18][64]: t1[r-1][j] = exp(-2 pi i j r/512), t2[s-1][j] = exp(-2 pi i (j&7) s/64), t3[m][j] = (cos, sin)(2 pi (j+64m)/1024)
+    const double2* win2;     // [M]  (w[2n], w[2n+1]),  M = nfft/2 = 64R
+    const double2* tw;       // [(R-1) + 7 + 4][64]: t1[r-1][j] = exp(-2 pi i j r/M), t2[s-1][j] = exp(-2 pi i (j&7) s/64),
+                             //                      t3[t][j] = (cos, sin)(2 pi ((j % 8R) + 8R t)/(2M))
     double scale;
     int k_lo, k_hi;          // MODE 2: bins of the band
 };
 
-template <bool DETREND, int MODE>    // MODE 0 psd, 1 magnitude, 2 band power: out[clip][frame] = sum of PSD bins [k_lo, k_hi] (A11)
-__global__ __launch_bounds__(64 * kWaves, kOcc) void stft1024_r8x3_f64_kernel(const R8DParams p) {
+template <int R> __device__ __forceinline__ void radix_first(cd* a);
+template <> __device__ __forceinline__ void radix_first<2>(cd* a) {
+    const cd s = cadd(a[0], a[1]), d = csub(a[0], a[1]);
+    a[0] = s; a[1] = d;
+}
+template <> __device__ __forceinline__ void radix_first<4>(cd* a) {
+    const cd s02 = cadd(a[0], a[2]), d02 = csub(a[0], a[2]);
+    const cd s13 = cadd(a[1], a[3]), d13 = mul_mi(csub(a[1], a[3]));
+    a[0] = cadd(s02, s13); a[2] = csub(s02, s13);
+    a[1] = cadd(d02, d13); a[3] = csub(d02, d13);
+}
+template <> __device__ __forceinline__ void radix_first<8>(cd* a) { radix8(*reinterpret_cast<cd(*)[8]>(a)); }
+
+template <int L> __device__ __forceinline__ double group_sum(double v) {     // over the L = 8R lanes that share a frame
+#pragma unroll
+    for (int o = L / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// R = nfft/128: 2 (256), 4 (512), 8 (1024).  A wave carries G = 8/R frames per step (stft_rsmall.hip; G = 1 is the r8x3 mapping).
+// MODE 0 psd, 1 magnitude, 2 band power: out[clip][frame] = sum of PSD bins [k_lo, k_hi] (A11)
+template <int R, bool DETREND, int MODE>
+__global__ __launch_bounds__(64 * kWaves, kOcc) void stft_reg_f64_kernel(const R8DParams p) {
+    constexpr int G = 8 / R, M = 64 * R, L = 8 * R, NB = M + 1, RS = M + 8;
+    static_assert(G * RS <= kSlab, "split regions must fit the slab");
     __shared__ __attribute__((aligned(16))) double lds[kWaves * 2 * kSlab];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -104,131 +129,166 @@ __global__ __launch_bounds__(64 * kWaves, kOcc) void stft1024_r8x3_f64_kernel(co
     const int lw = xcd_remap(blockIdx.x, gridDim.x) * kWaves + wave;
     if (lw >= p.n_waves) return;
 
-    cd w[8], t1[7], t2[7], t3[4];
+    cd w[R], t1[R - 1], t2[7], t3[4];
     const double sq = sqrt(MODE != 1 ? p.scale * 0.5 : p.scale * 0.25);      // PSD scale rides on the window (stft_r8x3.hip)
 #pragma unroll
-    for (int a = 0; a < 8; ++a) { const double2 v = p.win2[lane + 64 * a]; w[a] = {v.x * sq, v.y * sq}; }
+    for (int a = 0; a < R; ++a) { const double2 v = p.win2[lane + 64 * a]; w[a] = {v.x * sq, v.y * sq}; }
 #pragma unroll
-    for (int r = 0; r < 7; ++r) {
-        const double2 u = p.tw[r * 64 + lane], v = p.tw[(7 + r) * 64 + lane];
-        t1[r] = {u.x, u.y}; t2[r] = {v.x, v.y};
-    }
+    for (int r = 0; r < R - 1; ++r) { const double2 v = p.tw[r * 64 + lane]; t1[r] = {v.x, v.y}; }
 #pragma unroll
-    for (int m = 0; m < 4; ++m) { const double2 v = p.tw[(14 + m) * 64 + lane]; t3[m] = {v.x, v.y}; }
-    const double r0 = (MODE != 1 && lane == 0) ? 0.5 : 1.0;
+    for (int s = 0; s < 7; ++s) { const double2 v = p.tw[(R - 1 + s) * 64 + lane]; t2[s] = {v.x, v.y}; }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { const double2 v = p.tw[(R - 1 + 7 + t) * 64 + lane]; t3[t] = {v.x, v.y}; }
 
     const int j0 = lane & 7, hi = lane >> 3;
-    const int x1w = hi * kS1 + j0, x1r = lane, x2w = j0 * kS2 + hi, x2r = lane, x3w = lane, x3b = kM - lane;
+    const int x1w = hi * kS1 + j0, x1r = lane;                          // + 8 v   | + b kS1
+    const int x2w = j0 * kS2 + (hi % R) + L * (hi / R), x2r = lane;     // + R s   | + j kS2     (hi = g R + r here)
+    const int g3 = lane / L, lu = lane - g3 * L;
+    const int x3w = g3 * RS + lu, x3b = g3 * RS + (M - lu);             // + L t   | - L t
+    const double r0 = (MODE != 1 && lu == 0) ? 0.5 : 1.0;
 
-    int64_t g = p.total_frames * lw / p.n_waves;
-    const int64_t g_end = p.total_frames * (lw + 1) / p.n_waves;
-    while (g < g_end) {
-        const int clip = static_cast<int>(g / p.n_frames);
-        const int f0 = static_cast<int>(g - static_cast<int64_t>(clip) * p.n_frames);
-        const int f1 = static_cast<int>(min(static_cast<int64_t>(p.n_frames), f0 + (g_end - g)));
-        g += f1 - f0;
-        const double* src = p.x + static_cast<int64_t>(clip) * p.clip_stride + 2 * lane + static_cast<int64_t>(f0) * p.hop;
-        double* orow = p.out + static_cast<int64_t>(clip) * p.out_clip_stride + static_cast<int64_t>(f0) * (MODE == 2 ? 1 : kBins);
+    int64_t q = p.total_groups * lw / p.n_waves;
+    const int64_t q_end = p.total_groups * (lw + 1) / p.n_waves;
 
-        cd raw[8];
+    // the loads of group q+1 are issued before the FFT of group q
+    auto load_group = [&](int clip, int gi, cd (&dst)[8]) {
+        const double* const xclip = p.x + static_cast<int64_t>(clip) * p.clip_stride + 2 * lane;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { const double2 v = *reinterpret_cast<const double2*>(src + 128 * k); raw[k] = {v.x, v.y}; }
-        for (int f = f0; f < f1; ++f) {
-            cd a[8];
+        for (int g = 0; g < G; ++g) {
+            const int f = min(gi * G + g, p.n_frames - 1);               // partial last group: recompute the last frame
+            const double* const src = xclip + static_cast<int64_t>(f) * p.hop;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) a[k] = raw[k];
-            {   // prefetch the next frame (the run's last frame fetches itself again: an unconditional load keeps the compiler
-                // from parking a wait right behind it)
-                const double* const nxt = f + 1 < f1 ? src + p.hop : src;
-                src = nxt;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) { const double2 v = *reinterpret_cast<const double2*>(nxt + 128 * k); raw[k] = {v.x, v.y}; }
-            }
-            if (DETREND) {                                        // A3 (scipy:2191, detrend 'constant')
-                double s = a[0].x + a[0].y;
-#pragma unroll
-                for (int k = 1; k < 8; ++k) s += a[k].x + a[k].y;
-                const double mean = wave_sum(s) * (1.0 / kN);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) { a[k].x -= mean; a[k].y -= mean; }
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { a[k].x *= w[k].x; a[k].y *= w[k].y; }       // A4
-
-            // ---- pass 1 ----
-            radix8(a);
-#pragma unroll
-            for (int r = 1; r < 8; ++r) a[r] = cmul(a[r], t1[r - 1]);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) sl.put(x1w + 8 * r, a[r]);
-            wave_lds_fence();
-#pragma unroll
-            for (int b = 0; b < 8; ++b) a[b] = sl.get(x1r + b * kS1);
-            wave_lds_fence();
-            // ---- pass 2 ----
-            radix8(a);
-#pragma unroll
-            for (int s = 1; s < 8; ++s) a[s] = cmul(a[s], t2[s - 1]);
-#pragma unroll
-            for (int s = 0; s < 8; ++s) sl.put(x2w + 8 * s, a[s]);
-            wave_lds_fence();
-#pragma unroll
-            for (int j = 0; j < 8; ++j) a[j] = sl.get(x2r + j * kS2);
-            wave_lds_fence();
-            // ---- pass 3: Z[lane + 64 t] ----
-            radix8(a);
-#pragma unroll
-            for (int t = 4; t < 8; ++t) sl.put(x3w + 64 * t, a[t]);
-            sl.put(kM + lane, a[0]);                              // lane 0: Z[512] := Z[0]
-            wave_lds_fence();
-            // ---- split pass + |X|^2 (A5 tail, A6) ----
-            double bsum = 0.0;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const cd A = a[m];
-                const cd B = sl.get(x3b - 64 * m);
-                const cd cs = t3[m];
-                const cd S = {A.x + B.x, A.y - B.y};
-                const cd D = {A.x - B.x, A.y + B.y};
-                const cd T = {fma(cs.y, D.x, -cs.x * D.y), fma(cs.x, D.x, cs.y * D.y)};
-                const cd Xk = csub(S, T), Xm = cadd(S, T);
-                double pk = fma(Xk.x, Xk.x, Xk.y * Xk.y), pm = fma(Xm.x, Xm.x, Xm.y * Xm.y);
-                if (MODE != 1 && m == 0) { pk *= r0; pm *= r0; }
-                if (MODE == 1) { pk = sqrt(pk); pm = sqrt(pm); }
-                const int k = lane + 64 * m;
-                if (MODE == 2) {
-                    if (k >= p.k_lo && k <= p.k_hi) bsum += pk;
-                    if (kM - k >= p.k_lo && kM - k <= p.k_hi) bsum += pm;
-                } else {
-                    orow[k] = pk;
-                    orow[kM - k] = pm;
-                }
-            }
-            {
-                const double zx = __shfl(a[4].x, 0), zy = __shfl(a[4].y, 0);     // k = 256 pairs with itself: lane 0's a[4]
-                double pq = fma(zx, zx, zy * zy) * 4.0;
-                if (MODE == 1) pq = sqrt(pq);
-                if (MODE == 2) {
-                    if (lane == 0 && 256 >= p.k_lo && 256 <= p.k_hi) bsum += pq;
-                    bsum = wave_sum(bsum);
-                    if (lane == 0) orow[0] = bsum;
-                } else {
-                    orow[256] = pq;
-                }
-            }
-            orow += MODE == 2 ? 1 : kBins;
-            wave_lds_fence();
+            for (int k = 0; k < R; ++k) { const double2 v = *reinterpret_cast<const double2*>(src + 128 * k); dst[g * R + k] = {v.x, v.y}; }
         }
+    };
+    int clip = static_cast<int>(q / p.groups_per_clip);
+    int gi = static_cast<int>(q - static_cast<int64_t>(clip) * p.groups_per_clip);
+    cd nxt[8];
+    if (q < q_end) load_group(clip, gi, nxt);
+
+    for (; q < q_end; ++q) {
+        const int clip_n = gi + 1 == p.groups_per_clip ? clip + 1 : clip, gi_n = gi + 1 == p.groups_per_clip ? 0 : gi + 1;
+        const bool more = q + 1 < q_end;                                 // the run's last group fetches itself again (an
+        cd a[8];                                                         // unconditional load: no wait parked behind it)
+#pragma unroll
+        for (int v = 0; v < 8; ++v) a[v] = nxt[v];
+        load_group(more ? clip_n : clip, more ? gi_n : gi, nxt);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (DETREND) {                                               // A3 (scipy:2191, detrend 'constant')
+                double s = a[g * R].x + a[g * R].y;
+#pragma unroll
+                for (int k = 1; k < R; ++k) s += a[g * R + k].x + a[g * R + k].y;
+                const double mean = wave_sum(s) * (1.0 / (2 * M));
+#pragma unroll
+                for (int k = 0; k < R; ++k) { a[g * R + k].x -= mean; a[g * R + k].y -= mean; }
+            }
+#pragma unroll
+            for (int k = 0; k < R; ++k) { a[g * R + k].x *= w[k].x; a[g * R + k].y *= w[k].y; }       // A4
+            // ---- pass 1: G independent R-point DFTs ----
+            radix_first<R>(a + g * R);
+#pragma unroll
+            for (int r = 1; r < R; ++r) a[g * R + r] = cmul(a[g * R + r], t1[r - 1]);
+        }
+#pragma unroll
+        for (int v = 0; v < 8; ++v) sl.put(x1w + 8 * v, a[v]);
+        wave_lds_fence();
+#pragma unroll
+        for (int b = 0; b < 8; ++b) a[b] = sl.get(x1r + b * kS1);
+        wave_lds_fence();
+        // ---- pass 2 ----
+        radix8(a);
+#pragma unroll
+        for (int s = 1; s < 8; ++s) a[s] = cmul(a[s], t2[s - 1]);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) sl.put(x2w + R * s, a[s]);
+        wave_lds_fence();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = sl.get(x2r + j * kS2);
+        wave_lds_fence();
+        // ---- pass 3: lane lu of group g3 holds Z_g[lu + L t] ----
+        radix8(a);
+#pragma unroll
+        for (int t = 4; t < 8; ++t) sl.put(x3w + L * t, a[t]);
+        if (lu == 0) sl.put(g3 * RS + M, a[0]);                          // Z_g[M] := Z_g[0]
+        wave_lds_fence();
+        // ---- split pass + |X|^2 (A5 tail, A6) ----
+        const int f = gi * G + g3;
+        const bool live = f < p.n_frames;
+        double* const orow = p.out + static_cast<int64_t>(clip) * p.out_clip_stride +
+                             static_cast<int64_t>(min(f, p.n_frames - 1)) * (MODE == 2 ? 1 : NB);
+        double bsum = 0.0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const cd A = a[t];
+            const cd B = sl.get(x3b - L * t);
+            const cd cs = t3[t];
+            const cd S = {A.x + B.x, A.y - B.y};
+            const cd D = {A.x - B.x, A.y + B.y};
+            const cd T = {fma(cs.y, D.x, -cs.x * D.y), fma(cs.x, D.x, cs.y * D.y)};
+            const cd Xk = csub(S, T), Xm = cadd(S, T);
+            double pk = fma(Xk.x, Xk.x, Xk.y * Xk.y), pm = fma(Xm.x, Xm.x, Xm.y * Xm.y);
+            if (MODE != 1 && t == 0) { pk *= r0; pm *= r0; }
+            if (MODE == 1) { pk = sqrt(pk); pm = sqrt(pm); }
+            const int k = lu + L * t;
+            if (MODE == 2) {
+                if (k >= p.k_lo && k <= p.k_hi) bsum += pk;
+                if (M - k >= p.k_lo && M - k <= p.k_hi) bsum += pm;
+            } else if (live) {
+                orow[k] = pk;
+                orow[M - k] = pm;
+            }
+        }
+        {
+            double pq = fma(a[4].x, a[4].x, a[4].y * a[4].y) * 4.0;      // k = M/2 pairs with itself: lane lu == 0 holds Z[M/2]
+            if (MODE == 1) pq = sqrt(pq);
+            if (MODE == 2) {
+                if (lu == 0 && M / 2 >= p.k_lo && M / 2 <= p.k_hi) bsum += pq;
+                bsum = group_sum<L>(bsum);
+                if (live && lu == 0) orow[0] = bsum;
+            } else if (live && lu == 0) {
+                orow[M / 2] = pq;
+            }
+        }
+        wave_lds_fence();
+        clip = clip_n;
+        gi = gi_n;
     }
 }
 
-template <bool DETREND>
+template <int R, bool DETREND>
 int launch_mode(const R8DParams& prm, int n_wg, hipStream_t s, int mode, bool band) {
-    if (band) hipLaunchKernelGGL((stft1024_r8x3_f64_kernel<DETREND, 2>), dim3(n_wg), dim3(64 * kWaves), 0, s, prm);
-    else if (mode == SG_MODE_PSD) hipLaunchKernelGGL((stft1024_r8x3_f64_kernel<DETREND, 0>), dim3(n_wg), dim3(64 * kWaves), 0, s, prm);
-    else hipLaunchKernelGGL((stft1024_r8x3_f64_kernel<DETREND, 1>), dim3(n_wg), dim3(64 * kWaves), 0, s, prm);
+    if (band) hipLaunchKernelGGL((stft_reg_f64_kernel<R, DETREND, 2>), dim3(n_wg), dim3(64 * kWaves), 0, s, prm);
+    else if (mode == SG_MODE_PSD) hipLaunchKernelGGL((stft_reg_f64_kernel<R, DETREND, 0>), dim3(n_wg), dim3(64 * kWaves), 0, s, prm);
+    else hipLaunchKernelGGL((stft_reg_f64_kernel<R, DETREND, 1>), dim3(n_wg), dim3(64 * kWaves), 0, s, prm);
     hipError_t e = hipGetLastError();
-    return e == hipSuccess ? SG_OK : hip_fail(e, "stft1024_r8x3_f64 launch");
+    return e == hipSuccess ? SG_OK : hip_fail(e, "stft_reg_f64 launch");
+}
+
+template <int R>
+int launch_r(const sg_plan& p, const StftArgs& a) {
+    constexpr int G = 8 / R;
+    R8DParams prm{};
+    prm.x = static_cast<const double*>(a.x);
+    prm.clip_stride = a.clip_stride;
+    prm.n_frames = static_cast<int>(a.n_frames);
+    prm.hop = p.hop;
+    prm.groups_per_clip = static_cast<int>((a.n_frames + G - 1) / G);
+    prm.total_groups = static_cast<int64_t>(prm.groups_per_clip) * a.n_clips;
+    int64_t n_waves = static_cast<int64_t>(p.n_cu) * 4 * kOcc;
+    const int64_t by_work = (prm.total_groups + 3) / 4;
+    if (n_waves > by_work) n_waves = by_work;
+    prm.n_waves = static_cast<int>(n_waves);
+    prm.out = static_cast<double*>(a.out);
+    prm.out_clip_stride = a.out_clip_stride;
+    prm.win2 = static_cast<const double2*>(p.win_dev);
+    prm.tw = static_cast<const double2*>(p.r8_tw_dev);
+    prm.scale = p.scale;
+    prm.k_lo = a.k_lo; prm.k_hi = a.k_hi;
+    const int n_wg = static_cast<int>((n_waves + kWaves - 1) / kWaves);
+    const bool band = a.band_mode != 0;                     // run_stft has checked: psd plan, 0 <= k_lo <= k_hi < n_bins
+    return p.detrend == SG_DETREND_CONSTANT ? launch_mode<R, true>(prm, n_wg, a.stream, p.mode, band)
+                                            : launch_mode<R, false>(prm, n_wg, a.stream, p.mode, band);
 }
 
 }  // namespace
@@ -240,45 +300,26 @@ bool r8x3_f64_can_run(const sg_plan& p, const StftArgs& a) {
 
 int launch_r8x3_f64(const sg_plan& p, const StftArgs& a) {
     if (a.n_frames <= 0 || a.n_clips <= 0) return SG_OK;
-    R8DParams prm{};
-    prm.x = static_cast<const double*>(a.x);
-    prm.clip_stride = a.clip_stride;
-    prm.n_frames = static_cast<int>(a.n_frames);
-    prm.hop = p.hop;
-    prm.total_frames = a.n_frames * a.n_clips;
-    int64_t n_waves = static_cast<int64_t>(p.n_cu) * 4 * kOcc;
-    const int64_t by_work = (prm.total_frames + 3) / 4;
-    if (n_waves > by_work) n_waves = by_work;
-    prm.n_waves = static_cast<int>(n_waves);
-    prm.out = static_cast<double*>(a.out);
-    prm.out_clip_stride = a.out_clip_stride;
-    prm.win2 = static_cast<const double2*>(p.win_dev);
-    prm.tw = static_cast<const double2*>(p.r8_tw_dev);
-    prm.scale = p.scale;
-    prm.k_lo = a.k_lo; prm.k_hi = a.k_hi;
-    const int n_wg = static_cast<int>((n_waves + kWaves - 1) / kWaves);
-    const bool band = a.band_mode != 0;                     // run_stft has checked: psd plan, 0 <= k_lo <= k_hi < 513
-    return p.detrend == SG_DETREND_CONSTANT ? launch_mode<true>(prm, n_wg, a.stream, p.mode, band) : launch_mode<false>(prm, n_wg, a.stream, p.mode, band);
+    switch (p.nfft) {
+        case 256: return launch_r<2>(p, a);
+        case 512: return launch_r<4>(p, a);
+        default: return launch_r<8>(p, a);
+    }
 }
 
-// the [18][64] per-lane twiddle table of stft_r8x3.hip in double
+// the per-lane twiddle table [(R-1) + 7 + 4][64] of stft_rsmall.hip / stft_r8x3.hip (R = nfft/128) in double
 int build_r8x3_f64_tables(sg_plan& p) {
-    std::vector<double> tw(18 * 64 * 2);
+    const int R = p.nfft / 128, M = 64 * R, L = 8 * R;
+    std::vector<double> tw(static_cast<size_t>(R - 1 + 7 + 4) * 64 * 2);
     const long double two_pi = 6.283185307179586476925286766559005768L;
+    auto put = [&](int row, int j, long double ang) {
+        tw[2 * (static_cast<size_t>(row) * 64 + j)] = static_cast<double>(cosl(ang));
+        tw[2 * (static_cast<size_t>(row) * 64 + j) + 1] = static_cast<double>(sinl(ang));
+    };
     for (int j = 0; j < 64; ++j) {
-        for (int r = 1; r < 8; ++r) {
-            const long double a1 = -two_pi * static_cast<long double>((j * r) % 512) / 512.0L;
-            tw[2 * ((r - 1) * 64 + j)] = static_cast<double>(cosl(a1));
-            tw[2 * ((r - 1) * 64 + j) + 1] = static_cast<double>(sinl(a1));
-            const long double a2 = -two_pi * static_cast<long double>(((j & 7) * r) % 64) / 64.0L;
-            tw[2 * ((7 + r - 1) * 64 + j)] = static_cast<double>(cosl(a2));
-            tw[2 * ((7 + r - 1) * 64 + j) + 1] = static_cast<double>(sinl(a2));
-        }
-        for (int m = 0; m < 4; ++m) {
-            const long double a3 = two_pi * static_cast<long double>(j + 64 * m) / 1024.0L;
-            tw[2 * ((14 + m) * 64 + j)] = static_cast<double>(cosl(a3));
-            tw[2 * ((14 + m) * 64 + j) + 1] = static_cast<double>(sinl(a3));
-        }
+        for (int r = 1; r < R; ++r) put(r - 1, j, -two_pi * static_cast<long double>((j * r) % M) / M);
+        for (int s = 1; s < 8; ++s) put(R - 1 + s - 1, j, -two_pi * static_cast<long double>(((j & 7) * s) % 64) / 64.0L);
+        for (int t = 0; t < 4; ++t) put(R - 1 + 7 + t, j, two_pi * static_cast<long double>((j % L) + L * t) / (2.0L * M));
     }
     SG_HIP(hipMalloc(&p.r8_tw_dev, tw.size() * sizeof(double)));
     SG_HIP(hipMemcpy(p.r8_tw_dev, tw.data(), tw.size() * sizeof(double), hipMemcpyHostToDevice));

@@ -111,44 +111,53 @@ def test_r8x3_int16_input(sp):
     assert_spec_close(s, so, time_axis=-1)
 
 
-@pytest.mark.parametrize("hop,window,detrend,mode", [(896, ("tukey", 0.25), "constant", "psd"), (256, "hann", "constant", "psd"),
-                                                     (2, "hann", False, "psd"), (1024, "boxcar", False, "magnitude"),
-                                                     (334, ("tukey", 0.25), "constant", "magnitude"),
-                                                     (255, "hann", "constant", "psd")])      # odd hop: falls back to the LDS kernel
-def test_r8x3_f64_variants(sp, hop, window, detrend, mode):
-    """The reference's default nperseg on its float64 recordings: the double-precision register kernel (stft_r8x3_f64.hip)."""
+@pytest.mark.parametrize("nperseg", [1024, 512, 256])
+@pytest.mark.parametrize("hop_of,window,detrend,mode", [
+    (lambda n: n - n // 8, ("tukey", 0.25), "constant", "psd"),          # the reference's call
+    (lambda n: n // 4, "hann", "constant", "psd"),
+    (lambda n: 2, "hann", False, "psd"),
+    (lambda n: n, "boxcar", False, "magnitude"),
+    (lambda n: 2 * (n // 6), ("tukey", 0.25), "constant", "magnitude"),
+    (lambda n: n // 4 - 1, "hann", "constant", "psd"),                     # odd hop: the call falls back to the LDS kernel
+], ids=["ref", "quarter", "hop2", "nooverlap_mag", "third_mag", "odd"])
+def test_register_f64_variants(sp, nperseg, hop_of, window, detrend, mode):
+    """The reference's nperseg settings on its float64 recordings: the double-precision register kernels (stft_r8x3_f64.hip)."""
     from spectro import _capi
     from spectro.signal import plan_for
     from spectro.windows import get_window
-    rng = np.random.default_rng(1000 + hop)
-    n = 1024 + hop * 41 + 6
+    hop = hop_of(nperseg)
+    rng = np.random.default_rng(1000 + hop + nperseg)
+    n = nperseg + hop * 40 + 6                                # 41 frames: a partial last group at 256 / 512; even clip stride
+    n += n % 2
     x = rng.standard_normal((3, n)) * 0.4 + 1.5
-    kw = dict(fs=20000.0, nperseg=1024, window=window, noverlap=1024 - hop, detrend=detrend, mode=mode)
+    kw = dict(fs=20000.0, nperseg=nperseg, window=window, noverlap=nperseg - hop, detrend=detrend, mode=mode)
     f, t, s = sp.spectrogram(x, **kw)
     fo, to, so = orc.spectrogram(x, **kw)
     np.testing.assert_array_equal(f, fo)
     np.testing.assert_array_equal(t, to)
     _check(s, so, np.float64)
-    plan = plan_for(get_window(window, 1024), 1024, 1024, hop, _capi.DETREND[detrend], 20000.0, 0, _capi.MODE[mode], _capi.F64)
-    assert plan.kernel == "r8x3d"
-    # single clips at odd sample offsets of one buffer (8-byte aligned only) still work: the plan falls back per call
+    plan = plan_for(get_window(window, nperseg), nperseg, nperseg, hop, _capi.DETREND[detrend], 20000.0, 0, _capi.MODE[mode], _capi.F64)
+    assert plan.kernel == ("r8x3d" if nperseg == 1024 else "rsmalld")
     _, _, s1 = sp.spectrogram(x[1, 1:], **kw)
     _, _, so1 = orc.spectrogram(x[1, 1:], **kw)
     _check(s1, so1, np.float64)
 
 
-def test_r8x3_f64_matches_stockham_and_edges(sp):
+@pytest.mark.parametrize("nperseg", [1024, 512, 256])
+def test_register_f64_matches_stockham_and_edges(sp, nperseg):
     from spectro import _capi
     from spectro.signal import plan_for
     from spectro.windows import get_window
     rng = np.random.default_rng(77)
-    ns = 1024 + 896 * 9                                     # 10 frames per clip, 7 clips: fewer frames than waves on the chip
+    hop = nperseg - nperseg // 8
+    ns = nperseg + hop * 10                                 # 11 frames per clip (a partial last group at 256 / 512), 7 clips
     x = rng.standard_normal((7, ns))
     x[2] = 0.0                                              # all-zero clip
     x[3] = 3.25                                             # constant clip: detrended to exact zeros
-    plan = plan_for(get_window(("tukey", 0.25), 1024), 1024, 1024, 896, 1, 20000.0, 0, 0, _capi.F64)
-    assert plan.kernel == "r8x3d"
-    nfr, nb = plan.n_frames(ns), 513
+    family = "r8x3d" if nperseg == 1024 else "rsmalld"
+    plan = plan_for(get_window(("tukey", 0.25), nperseg), nperseg, nperseg, hop, 1, 20000.0, 0, 0, _capi.F64)
+    assert plan.kernel == family
+    nfr, nb = plan.n_frames(ns), nperseg // 2 + 1
     d_in, d_a, d_b = _capi.DeviceBuffer(x.nbytes), _capi.DeviceBuffer(7 * nfr * nb * 8), _capi.DeviceBuffer(7 * nfr * nb * 8)
     d_in.upload(x)
     plan.stft(d_in.ptr, ns, ns, 7, d_a.ptr, nfr * nb)
@@ -156,18 +165,19 @@ def test_r8x3_f64_matches_stockham_and_edges(sp):
     try:
         plan.stft(d_in.ptr, ns, ns, 7, d_b.ptr, nfr * nb)
     finally:
-        plan.force_kernel("r8x3d")
+        plan.force_kernel(family)
     a, b = np.empty((7, nfr, nb)), np.empty((7, nfr, nb))
     d_a.download(a)
     d_b.download(b)
     _capi.stream_sync()
     _check(np.moveaxis(a, 1, 2), np.moveaxis(b, 1, 2), np.float64)
     assert np.all(a[2] == 0.0) and np.all(a[3] == 0.0)
-    _, _, so = orc.spectrogram(x, fs=20000.0, nperseg=1024)
+    _, _, so = orc.spectrogram(x, fs=20000.0, nperseg=nperseg)
     _check(np.moveaxis(a, 1, 2), so, np.float64)
     # fused band power (A11) on the same kernel: per-frame sums of bins [k_lo, k_hi], the spectrum is never written
     d_bp = _capi.DeviceBuffer(7 * nfr * 8)
-    for k_lo, k_hi in [(0, 512), (3, 40), (256, 256), (255, 257), (257, 300), (0, 0), (512, 512), (100, 511)]:
+    h = nperseg // 2
+    for k_lo, k_hi in [(0, h), (3, 40), (h // 2, h // 2), (h // 2 - 1, h // 2 + 1), (h // 2 + 1, h - 12), (0, 0), (h, h), (100, h - 1)]:
         plan.band_power(d_in.ptr, ns, ns, 7, k_lo, k_hi, d_bp.ptr, nfr)
         bp = np.empty((7, nfr))
         d_bp.download(bp)
@@ -179,10 +189,12 @@ def test_r8x3_f64_matches_stockham_and_edges(sp):
     b1 = np.empty((plan.n_frames(ns - 1), nb))
     d_b.download(b1)
     _capi.stream_sync()
-    _, _, so1 = orc.spectrogram(x[0, 1:], fs=20000.0, nperseg=1024)
+    _, _, so1 = orc.spectrogram(x[0, 1:], fs=20000.0, nperseg=nperseg)
     _check(b1.T, so1, np.float64)
     with pytest.raises(NotImplementedError):
         plan_for(get_window("hann", 1024), 1024, 1024, 256, 1, 1.0, 0, 0, _capi.F32).force_kernel("r8x3d")
+    with pytest.raises(NotImplementedError):
+        plan.force_kernel("rsmalld" if nperseg == 1024 else "r8x3d")
 
 
 def test_full_size_properties(sp):
