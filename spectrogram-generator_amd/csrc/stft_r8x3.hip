@@ -474,7 +474,8 @@ int r8x3_grid_waves(const sg_plan& p, int64_t total_frames, bool mel) {
     if (const char* e = getenv("SPECTRO_R8_OCC")) { const int v = atoi(e); if (v >= 1 && v <= kOccupancy) occ = v; }   // tuning aid
     int64_t n_waves = static_cast<int64_t>(p.n_cu) * 4 * occ;
     if (const char* e = getenv("SPECTRO_R8_WAVES")) { const long v = atol(e); if (v >= 64 && v <= 65536) n_waves = v; }          // tuning aid
-    const int64_t by_work = (total_frames + kMinRun - 1) / kMinRun;
+    // GUI-sized calls (fewer frames than waves the chip holds): one frame per wave, latency before efficiency
+    const int64_t by_work = total_frames <= n_waves ? total_frames : (total_frames + kMinRun - 1) / kMinRun;
     if (n_waves > by_work) n_waves = by_work;
     return static_cast<int>(n_waves);
 }

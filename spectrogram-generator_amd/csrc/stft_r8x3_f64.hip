@@ -276,8 +276,7 @@ int launch_r(const sg_plan& p, const StftArgs& a) {
     prm.groups_per_clip = static_cast<int>((a.n_frames + G - 1) / G);
     prm.total_groups = static_cast<int64_t>(prm.groups_per_clip) * a.n_clips;
     int64_t n_waves = static_cast<int64_t>(p.n_cu) * 4 * kOcc;
-    const int64_t by_work = (prm.total_groups + 3) / 4;
-    if (n_waves > by_work) n_waves = by_work;
+    if (n_waves > prm.total_groups) n_waves = prm.total_groups;      // GUI-sized calls: one group per wave, latency before efficiency
     prm.n_waves = static_cast<int>(n_waves);
     prm.out = static_cast<double*>(a.out);
     prm.out_clip_stride = a.out_clip_stride;
