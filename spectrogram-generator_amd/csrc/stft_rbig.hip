@@ -47,6 +47,7 @@ struct BigParams {
     const float2* win2;       // [M]
     const float2* tw;         // [(R-1) + 7 + R/2][64]
     float scale;
+    int k_lo, k_hi;           // MODE 2: bins of the band
 };
 
 template <int T> __device__ __forceinline__ void radix_t(float2 (&v)[T]);
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(64 * WavesFor<T>::value, T == 4 ? SG_RBIG4_OCC : 4)
     float2* const buf = lds + kTabs + wave * kSlab;
 
     // sqrt of the PSD scale rides on the window table (stft_r8x3.hip); per frame only the 1/2 on bins 0 and M is left
-    const float q_in = MODE == 0 ? p.scale * 0.5f : p.scale * 0.25f;
+    const float q_in = MODE != 1 ? p.scale * 0.5f : p.scale * 0.25f;
     {
         const float sq = sqrtf(q_in);
         for (int i = threadIdx.x; i < M; i += 64 * kWaves) { const float2 wv = p.win2[i]; lds[i] = make_float2(wv.x * sq, wv.y * sq); }
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(64 * WavesFor<T>::value, T == 4 ? SG_RBIG4_OCC : 4)
     float2* const x3w = buf + lane;                          // + 64*slot, 4 upper blocks per group
     const float2* const x3b = buf + (256 - lane);            // - 64*(c - 4i)
 
-    const float r0 = (MODE == 0 && lane == 0) ? 0.5f : 1.0f;
+    const float r0 = (MODE != 1 && lane == 0) ? 0.5f : 1.0f;
 
     // T = 2 fetches the samples of frame g+1 at the top of frame g (+32 VGPRs throughout).  T = 4 has no registers to
     // spare and loads at the top of the frame; fetching late, as the split pass frees registers, or whole frames ahead at
@@ -125,7 +126,8 @@ __global__ __launch_bounds__(64 * WavesFor<T>::value, T == 4 ? SG_RBIG4_OCC : 4)
     if (kPrefetch && g < g_end) load_frame(clip, f, reinterpret_cast<float2 (&)[T][8]>(nxt));
 
     for (; g < g_end; ++g) {
-        float* const orow = p.out + static_cast<int64_t>(clip) * p.out_clip_stride + static_cast<int64_t>(f) * NB;
+        float* const orow = p.out + static_cast<int64_t>(clip) * p.out_clip_stride + static_cast<int64_t>(f) * (MODE == 2 ? 1 : NB);
+        float bsum = 0.f;                                    // MODE 2: this lane's share of the band sum (A11)
         const int clip_n = f + 1 == p.n_frames ? clip + 1 : clip, f_n = f + 1 == p.n_frames ? 0 : f + 1;
 
         float2 d[T][8];
@@ -246,11 +248,16 @@ __global__ __launch_bounds__(64 * WavesFor<T>::value, T == 4 ? SG_RBIG4_OCC : 4)
                 const float2 Xk = csub(S, Tt), Xm = cadd(S, Tt);
                 float pk = fmaf(Xk.x, Xk.x, Xk.y * Xk.y);
                 float pm = fmaf(Xm.x, Xm.x, Xm.y * Xm.y);
-                if (MODE == 0 && c == 0) { pk *= r0; pm *= r0; }
+                if (MODE != 1 && c == 0) { pk *= r0; pm *= r0; }
                 if (MODE == 1) { pk = sqrtf(pk); pm = sqrtf(pm); }
                 const int k = lane + 64 * c;
-                orow[k] = pk;
-                orow[M - k] = pm;
+                if (MODE == 2) {
+                    if (k >= p.k_lo && k <= p.k_hi) bsum += pk;
+                    if (M - k >= p.k_lo && M - k <= p.k_hi) bsum += pm;
+                } else {
+                    orow[k] = pk;
+                    orow[M - k] = pm;
+                }
             }
             wave_lds_fence();
         }
@@ -261,18 +268,25 @@ __global__ __launch_bounds__(64 * WavesFor<T>::value, T == 4 ? SG_RBIG4_OCC : 4)
             const float zy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, SG_Z(R / 2).y), 0));
             float pq = fmaf(zx, zx, zy * zy) * 4.0f;
             if (MODE == 1) pq = sqrtf(pq);
-            orow[M / 2] = pq;                                // wave-uniform store
+            if (MODE == 2) {
+                if (lane == 0 && M / 2 >= p.k_lo && M / 2 <= p.k_hi) bsum += pq;
+                bsum = wave_sum(bsum);
+                if (lane == 0) orow[0] = bsum;
+            } else {
+                orow[M / 2] = pq;                            // wave-uniform store
+            }
         }
 #undef SG_Z
     }
 }
 
 template <int T, bool DETREND>
-int launch_td(const BigParams& prm, int n_wg, size_t lds, hipStream_t s, int mode) {
+int launch_td(const BigParams& prm, int n_wg, size_t lds, hipStream_t s, int mode, bool band) {
     constexpr int kWaves = WavesFor<T>::value;
     auto k0 = stft_rbig_kernel<T, DETREND, 0>;
     auto k1 = stft_rbig_kernel<T, DETREND, 1>;
-    auto kern = mode == SG_MODE_PSD ? k0 : k1;
+    auto k2 = stft_rbig_kernel<T, DETREND, 2>;
+    auto kern = band ? k2 : mode == SG_MODE_PSD ? k0 : k1;
     if (lds > 64 * 1024)
         SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     hipLaunchKernelGGL(kern, dim3(n_wg), dim3(64 * kWaves), lds, s, prm);
@@ -299,15 +313,17 @@ int launch_t(const sg_plan& p, const StftArgs& a) {
     prm.win2 = static_cast<const float2*>(p.win_dev);
     prm.tw = static_cast<const float2*>(p.r8_tw_dev);
     prm.scale = static_cast<float>(p.scale);
+    prm.k_lo = a.k_lo; prm.k_hi = a.k_hi;
     const int n_wg = static_cast<int>((n_waves + kWaves - 1) / kWaves);
-    return p.detrend == SG_DETREND_CONSTANT ? launch_td<T, true>(prm, n_wg, lds, a.stream, p.mode)
-                                            : launch_td<T, false>(prm, n_wg, lds, a.stream, p.mode);
+    const bool band = a.band_mode != 0;                    // run_stft has checked: psd plan, 0 <= k_lo <= k_hi < n_bins
+    return p.detrend == SG_DETREND_CONSTANT ? launch_td<T, true>(prm, n_wg, lds, a.stream, p.mode, band)
+                                            : launch_td<T, false>(prm, n_wg, lds, a.stream, p.mode, band);
 }
 
 }  // namespace
 
 bool rbig_can_run(const sg_plan& p, const StftArgs& a) {
-    return !a.in_i16 && !a.band_mode && (p.hop % 2 == 0) && (a.clip_stride % 2 == 0 || a.n_clips == 1) &&
+    return !a.in_i16 && (p.hop % 2 == 0) && (a.clip_stride % 2 == 0 || a.n_clips == 1) &&
            (reinterpret_cast<uintptr_t>(a.x) % 8 == 0) && a.n_frames <= INT32_MAX;
 }
 

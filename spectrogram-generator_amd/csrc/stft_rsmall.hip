@@ -38,7 +38,14 @@ struct SmallParams {
     const float2* win2;       // [M] pairs (w[2n], w[2n+1])
     const float2* tw;         // [(R-1) + 7 + 4][64]
     float scale;
+    int k_lo, k_hi;           // MODE 2: bins of the band
 };
+
+template <int L> __device__ __forceinline__ float group_sum(float v) {      // over the L = 8R lanes that share a frame
+#pragma unroll
+    for (int o = L / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
 
 template <int R> __device__ __forceinline__ void radix_small(float2* a);
 template <> __device__ __forceinline__ void radix_small<2>(float2* a) {
@@ -52,6 +59,7 @@ template <> __device__ __forceinline__ void radix_small<4>(float2* a) {
     a[1] = cadd(d02, d13); a[3] = csub(d02, d13);
 }
 
+// MODE 0 psd, 1 magnitude, 2 band power: out[clip][frame] = sum of PSD bins [k_lo, k_hi] (A11, the spectrum is never written)
 template <int R, bool DETREND, int MODE>
 __global__ __launch_bounds__(64 * kWaves) void stft_rsmall_kernel(const SmallParams p) {
     constexpr int G = 8 / R, M = 64 * R, L = 8 * R, NB = M + 1, RS = M + 8;
@@ -87,13 +95,13 @@ __global__ __launch_bounds__(64 * kWaves) void stft_rsmall_kernel(const SmallPar
     const float2* const x3b = buf + g3 * RS + (M - lu);               // - L*t
 
     // sqrt of the PSD scale rides on the window registers (stft_r8x3.hip); per group only the 1/2 on bins 0 and M is left
-    const float q_in = MODE == 0 ? p.scale * 0.5f : p.scale * 0.25f;
+    const float q_in = MODE != 1 ? p.scale * 0.5f : p.scale * 0.25f;
     {
         const float sq = sqrtf(q_in);
 #pragma unroll
         for (int a = 0; a < R; ++a) { w[a].x *= sq; w[a].y *= sq; }
     }
-    const float r0 = (MODE == 0 && lu == 0) ? 0.5f : 1.0f;
+    const float r0 = (MODE != 1 && lu == 0) ? 0.5f : 1.0f;
 
     // loads of group q+1 are issued before the FFT of group q (one group of register prefetch)
     auto load_group = [&](int clip, int gi, float2 (&dst)[8]) {
@@ -168,7 +176,9 @@ __global__ __launch_bounds__(64 * kWaves) void stft_rsmall_kernel(const SmallPar
         if (SG_RSMALL_PRIO) __builtin_amdgcn_s_setprio(3);
         const int f = fg + g3;
         const bool live = f < p.n_frames;
-        float* const orow = p.out + static_cast<int64_t>(clip) * p.out_clip_stride + static_cast<int64_t>(min(f, p.n_frames - 1)) * NB;
+        float* const orow = p.out + static_cast<int64_t>(clip) * p.out_clip_stride +
+                            static_cast<int64_t>(min(f, p.n_frames - 1)) * (MODE == 2 ? 1 : NB);
+        float bsum = 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const float2 A = a[t];
@@ -180,18 +190,27 @@ __global__ __launch_bounds__(64 * kWaves) void stft_rsmall_kernel(const SmallPar
             const float2 Xk = csub(S, T), Xm = cadd(S, T);
             float pk = fmaf(Xk.x, Xk.x, Xk.y * Xk.y);
             float pm = fmaf(Xm.x, Xm.x, Xm.y * Xm.y);
-            if (MODE == 0 && t == 0) { pk *= r0; pm *= r0; }
+            if (MODE != 1 && t == 0) { pk *= r0; pm *= r0; }
             if (MODE == 1) { pk = sqrtf(pk); pm = sqrtf(pm); }
             const int k = lu + L * t;
-            if (live) {
+            if (MODE == 2) {
+                if (k >= p.k_lo && k <= p.k_hi) bsum += pk;
+                if (M - k >= p.k_lo && M - k <= p.k_hi) bsum += pm;
+            } else if (live) {
                 orow[k] = pk;
                 orow[M - k] = pm;
             }
         }
-        if (live && lu == 0) {                                         // k = M/2 pairs with itself: |Z[M/2]|^2
-            float pq = fmaf(a[4].x, a[4].x, a[4].y * a[4].y) * 4.0f;
+        {
+            float pq = fmaf(a[4].x, a[4].x, a[4].y * a[4].y) * 4.0f;  // k = M/2 pairs with itself: lane lu == 0 holds Z[M/2]
             if (MODE == 1) pq = sqrtf(pq);
-            orow[M / 2] = pq;
+            if (MODE == 2) {
+                if (lu == 0 && M / 2 >= p.k_lo && M / 2 <= p.k_hi) bsum += pq;
+                bsum = group_sum<L>(bsum);
+                if (live && lu == 0) orow[0] = bsum;
+            } else if (live && lu == 0) {
+                orow[M / 2] = pq;
+            }
         }
         wave_lds_fence();
         clip = clip_n;
@@ -200,8 +219,9 @@ __global__ __launch_bounds__(64 * kWaves) void stft_rsmall_kernel(const SmallPar
 }
 
 template <int R, bool DETREND>
-int launch_rd(const SmallParams& prm, int n_wg, hipStream_t s, int mode) {
-    if (mode == SG_MODE_PSD) hipLaunchKernelGGL((stft_rsmall_kernel<R, DETREND, 0>), dim3(n_wg), dim3(64 * kWaves), 0, s, prm);
+int launch_rd(const SmallParams& prm, int n_wg, hipStream_t s, int mode, bool band) {
+    if (band) hipLaunchKernelGGL((stft_rsmall_kernel<R, DETREND, 2>), dim3(n_wg), dim3(64 * kWaves), 0, s, prm);
+    else if (mode == SG_MODE_PSD) hipLaunchKernelGGL((stft_rsmall_kernel<R, DETREND, 0>), dim3(n_wg), dim3(64 * kWaves), 0, s, prm);
     else hipLaunchKernelGGL((stft_rsmall_kernel<R, DETREND, 1>), dim3(n_wg), dim3(64 * kWaves), 0, s, prm);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? SG_OK : hip_fail(e, "stft_rsmall launch");
@@ -227,17 +247,19 @@ int launch_r(const sg_plan& p, const StftArgs& a) {
     prm.win2 = static_cast<const float2*>(p.win_dev);
     prm.tw = static_cast<const float2*>(p.r8_tw_dev);
     prm.scale = static_cast<float>(p.scale);
+    prm.k_lo = a.k_lo; prm.k_hi = a.k_hi;
     const int n_wg = static_cast<int>((n_waves + kWaves - 1) / kWaves);
-    return p.detrend == SG_DETREND_CONSTANT ? launch_rd<R, true>(prm, n_wg, a.stream, p.mode)
-                                            : launch_rd<R, false>(prm, n_wg, a.stream, p.mode);
+    const bool band = a.band_mode != 0;                    // run_stft has checked: psd plan, 0 <= k_lo <= k_hi < n_bins
+    return p.detrend == SG_DETREND_CONSTANT ? launch_rd<R, true>(prm, n_wg, a.stream, p.mode, band)
+                                            : launch_rd<R, false>(prm, n_wg, a.stream, p.mode, band);
 }
 
 }  // namespace
 
-// The register path needs 8-byte aligned float2 loads and writes whole spectra; everything else (int16 input, odd
-// hops, fused band sums) is served by the Stockham kernel of the same plan.
+// The register path needs 8-byte aligned float2 loads; everything else (int16 input, odd hops) is served by the
+// Stockham kernel of the same plan.
 bool rsmall_can_run(const sg_plan& p, const StftArgs& a) {
-    return !a.in_i16 && !a.band_mode && (p.hop % 2 == 0) && (a.clip_stride % 2 == 0 || a.n_clips == 1) &&
+    return !a.in_i16 && (p.hop % 2 == 0) && (a.clip_stride % 2 == 0 || a.n_clips == 1) &&
            (reinterpret_cast<uintptr_t>(a.x) % 8 == 0) && a.n_frames <= INT32_MAX;
 }
 

@@ -6,6 +6,7 @@ Tolerance (fp32 path, BASELINE.md §2 / SURVEY H2), written out in conftest.asse
   per-bin rtol 1e-4 for bins >= 1e-3 * frame max.
 f64 path: 1e-11 relative to the frame max.  Frame indexing, f and t: bit-exact.
 """
+import ctypes as C
 import json
 import warnings
 
@@ -195,6 +196,44 @@ def test_register_f64_matches_stockham_and_edges(sp, nperseg):
         plan_for(get_window("hann", 1024), 1024, 1024, 256, 1, 1.0, 0, 0, _capi.F32).force_kernel("r8x3d")
     with pytest.raises(NotImplementedError):
         plan.force_kernel("rsmalld" if nperseg == 1024 else "r8x3d")
+
+
+@pytest.mark.parametrize("nperseg,hop,family", [(256, 64, "rsmall"), (512, 448, "rsmall"), (1024, 256, "r8x3"), (2048, 128, "rbig"),
+                                                (4096, 1024, "rbig"), (1024, 256, "stockham")])
+def test_fused_band_power_every_f32_family(sp, nperseg, hop, family):
+    """A11 fused into the transform (sg_stft_band_power): the per-frame band sum must equal the sum over the written spectrum's
+    bins, for the register kernels (round 2: rsmall and rbig too -- the parameter sweep's reduced product no longer falls back
+    to the LDS kernel) and for the LDS kernel itself."""
+    from spectro import _capi
+    from spectro.signal import plan_for
+    from spectro.windows import get_window
+    rng = np.random.default_rng(nperseg + hop)
+    ns = nperseg + hop * 21 + 2                              # 22 frames: a partial last group for rsmall
+    x = (rng.standard_normal((5, ns)) * 0.3 + 0.5).astype(np.float32)
+    plan = plan_for(get_window("hann", nperseg), nperseg, nperseg, hop, 1, 48000.0, 0, 0, _capi.F32)
+    restore = plan.kernel
+    if family == "stockham":
+        plan.force_kernel("stockham")
+    try:
+        assert plan.kernel == family
+        nfr, nb = plan.n_frames(ns), nperseg // 2 + 1
+        d_in, d_s, d_bp = _capi.DeviceBuffer(x.nbytes), _capi.DeviceBuffer(5 * nfr * nb * 4), _capi.DeviceBuffer(5 * nfr * 4)
+        d_in.upload(x)
+        plan.stft(d_in.ptr, ns, ns, 5, d_s.ptr, nfr * nb)
+        spec = np.empty((5, nfr, nb), np.float32)
+        d_s.download(spec)
+        _capi.stream_sync()
+        h = nperseg // 2
+        for k_lo, k_hi in [(0, h), (1, 7), (h // 2, h // 2), (h // 2 - 1, h // 2 + 1), (h // 2 + 1, h - 3), (0, 0), (h, h), (65, h - 1)]:
+            _capi.check(_capi.lib().sg_memset(C.c_void_p(d_bp.ptr), 0xFF, 5 * nfr * 4, None))
+            plan.band_power(d_in.ptr, ns, ns, 5, k_lo, k_hi, d_bp.ptr, nfr)
+            bp = np.empty((5, nfr), np.float32)
+            d_bp.download(bp)
+            _capi.stream_sync()
+            ref = spec[:, :, k_lo:k_hi + 1].astype(np.float64).sum(-1)
+            assert np.all(np.abs(bp - ref) <= 2e-6 * spec.astype(np.float64).sum(-1) + 1e-30), (k_lo, k_hi)
+    finally:
+        plan.force_kernel(restore)
 
 
 def test_full_size_properties(sp):
