@@ -3,7 +3,9 @@
 Default (batched) form: every rank owns a CONTIGUOUS run of clips for every ``(n_fft, hop)`` pair -- the remainders of
 ``n_clips / world`` rotate with the pair index so the ranks stay balanced -- uploads the clips it owns ONCE and runs
 ONE batched device call per pair (``DeviceClips.band_log_power``: fused band power + log10, two launches), i.e. at most
-``len(n_ffts) * len(hops)`` calls per rank instead of one launch and one upload per (clip, pair) item.  Plans (window /
+``len(n_ffts) * len(hops)`` calls per rank instead of one launch and one upload per (clip, pair) item.  Hops of one n_fft that
+divide each other share ONE transform at their gcd (``hop_families``: frame i at hop h IS frame i*h/g at hop g), so BASELINE cfg4's
+15 pairs cost 5 transforms -- 1 unit of work per n_fft instead of 1 + 1/2 + 1/4.  Plans (window /
 twiddle tables) are replicated per GPU; there is no data-path collective.  What crosses xGMI at the end is a *reduced*
 product per item (the per-frame log band power ``[n_frames]``, A11's fused kernel), gathered to the root with direct
 peer sends (``gather_to_root``) -- a full-spectrum gather would dwarf the compute.
@@ -24,7 +26,7 @@ import numpy as np
 
 from . import dist as sdist
 
-__all__ = ["work_items", "clip_blocks", "sharded_sweep"]
+__all__ = ["work_items", "clip_blocks", "hop_families", "sharded_sweep"]
 
 
 def work_items(n_clips: int, n_samples: int, n_ffts: Sequence[int], hops: Sequence[int]):
@@ -61,6 +63,28 @@ def clip_blocks(n_clips: int, n_ffts: Sequence[int], hops: Sequence[int], world:
     return out
 
 
+def hop_families(hops: Sequence[int]):
+    """Hops that can share ONE transform per n_fft: frame ``i`` at hop ``h`` is frame ``i * h/g`` at hop ``g`` when ``g`` divides
+    ``h`` (same samples, same arithmetic: bit-identical rows), so a family ``{h_i}`` is served by the hop-``g`` transform with
+    ``g = gcd(h_i)`` and row subsampling -- cfg4's hops 64 / 128 / 256 cost 1 unit of work instead of 1 + 1/2 + 1/4.  A hop
+    joins a family only while the shared transform stays cheaper than separate ones (``1/g <= sum 1/h_i``).
+    -> ``[(g, [h, ...]), ...]``, deterministic."""
+    from math import gcd
+    rest = sorted({int(h) for h in hops})
+    out = []
+    while rest:
+        fam = [rest.pop(0)]
+        g = fam[0]
+        for h in list(rest):
+            g2 = gcd(g, h)
+            if 1.0 / g2 <= sum(1.0 / m for m in fam) + 1.0 / h + 1e-12:
+                fam.append(h)
+                rest.remove(h)
+                g = g2
+        out.append((g, fam))
+    return out
+
+
 def _default_compute(clips, fs, fmin, fmax, window):
     from . import engine
 
@@ -83,6 +107,18 @@ def _default_batch(fs, fmin, fmax, window):
             if feats is None:
                 return np.zeros((b - a, 0), np.float32)
             return np.ascontiguousarray(feats[..., 0], np.float32)
+
+        def family(n_fft, g, members):
+            """``members = [(hop, a, b), ...]`` with ``g | hop``: one hop-``g`` transform over the hull of the clip ranges,
+            every member's rows taken from it.  -> list of ``[b - a, n_frames(hop)]`` f32 in member order"""
+            a0, b0 = min(m[1] for m in members), max(m[2] for m in members)
+            base = run(n_fft, g, a0, b0)
+            out = []
+            for hop, a, b in members:
+                nfr = sdist.n_frames(dev.n_samples, n_fft, hop)
+                out.append(np.ascontiguousarray(base[a - a0:b - a0, ::hop // g][:, :nfr]))
+            return out
+        run.family = family
         run.close = dev.free
         return run
     return open_batch
@@ -90,13 +126,15 @@ def _default_batch(fs, fmin, fmax, window):
 
 def sharded_sweep(clips, fs: float, n_ffts: Sequence[int], hops: Sequence[int], fmin: float = 0.0, fmax: float = 1e9,
                   window="hann", compute: Callable | None = None, dst: int = 0, batched: bool = True,
-                  batch_compute: Callable | None = None):
+                  batch_compute: Callable | None = None, share_hops: bool = True):
     """Run the sweep on this rank's share and gather the reduced results on ``dst``.
 
     ``clips``: ``[n_clips, n_samples]`` host array, identical on every rank (each rank only touches its own share).
     Batched (default): ``batch_compute(x_hull) -> run(n_fft, hop, a, b) -> [b - a, n_frames] f32`` over clips ``a..b`` of the
     hull it was given (default: log band power per frame through ``DeviceClips``); per item: ``compute(clip, n_fft, hop) -> 1-D float32`` (default: the same
-    product, one call per item).  Returns on ``dst`` a dict ``{(clip, n_fft, hop): array}`` for ALL items, elsewhere None.
+    product, one call per item).  ``share_hops`` (batched form, runners that offer ``family``): hops of one n_fft that divide
+    each other are served by one transform at their gcd and row subsampling (``hop_families``) -- identical values, cfg4's
+    15 pairs cost 5 transforms.  Returns on ``dst`` a dict ``{(clip, n_fft, hop): array}`` for ALL items, elsewhere None.
     """
     import torch
     clips = np.asarray(clips)
@@ -120,15 +158,26 @@ def sharded_sweep(clips, fs: float, n_ffts: Sequence[int], hops: Sequence[int], 
     lo = min(b[rank][0] for b in blocks.values())
     hi = max(b[rank][1] for b in blocks.values())
     opener = batch_compute or _default_batch(fs, fmin, fmax, window)
-    mine = []
     run = opener(clips[lo:hi]) if hi > lo else None             # ONE upload: the hull of this rank's clip ranges
+    done = {}
     try:
+        if run is not None and share_hops and hasattr(run, "family"):
+            for n in dict.fromkeys(int(n) for n in n_ffts):
+                for g, fam in hop_families(hops):
+                    members = [(h, blocks[(n, h)][rank][0] - lo, blocks[(n, h)][rank][1] - lo) for h in fam
+                               if blocks[(n, h)][rank][1] > blocks[(n, h)][rank][0]]
+                    if len(members) > 1:                         # one transform at hop g for the whole family
+                        for (h, _, _), arr in zip(members, run.family(n, g, members)):
+                            done[(n, h)] = np.ascontiguousarray(np.asarray(arr, np.float32))
+        mine = []
         for pair, ranges in blocks.items():
             c0, c1 = ranges[rank]
             if c1 <= c0:
                 mine.append(np.zeros((0, 0), np.float32))
-                continue
-            mine.append(np.ascontiguousarray(np.asarray(run(pair[0], pair[1], c0 - lo, c1 - lo), np.float32)))   # one batched call
+            elif pair in done:
+                mine.append(done[pair])
+            else:
+                mine.append(np.ascontiguousarray(np.asarray(run(pair[0], pair[1], c0 - lo, c1 - lo), np.float32)))   # one batched call
     finally:
         if run is not None and hasattr(run, "close"):
             run.close()

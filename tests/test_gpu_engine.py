@@ -311,6 +311,11 @@ def test_sharded_sweep_single_rank_on_device():
     per_item = sweep.sharded_sweep(clips, 48000.0, [256, 1024, 4096], [64, 256], fmin=200.0, fmax=8000.0, batched=False)
     for k, v in per_item.items():
         assert np.array_equal(v, res[k]), k
+    # hop sharing (64 and 256 of one n_fft come from ONE hop-64 transform) changes no bit
+    separate = sweep.sharded_sweep(clips, 48000.0, [256, 512, 1024, 2048, 4096], [64, 256], fmin=200.0, fmax=8000.0, share_hops=False)
+    assert separate.keys() == res.keys()
+    for k, v in separate.items():
+        assert np.array_equal(v, res[k]), k
 
 
 def test_device_clips_products_vs_oracle():

@@ -247,6 +247,18 @@ def test_shard_arithmetic():
     assert max(loads) / (sum(loads) / 8) < 1.15
 
 
+def test_hop_families():
+    from spectro.sweep import hop_families
+    assert hop_families([64, 128, 256]) == [(64, [64, 128, 256])]            # BASELINE cfg4: one transform per n_fft
+    assert hop_families([256, 64, 128, 64]) == [(64, [64, 128, 256])]
+    assert hop_families([64, 96]) == [(64, [64]), (96, [96])]                  # gcd 32 would cost more than both
+    assert hop_families([100]) == [(100, [100])]
+    assert hop_families([32, 48, 64]) == [(32, [32, 64]), (48, [48])]
+    assert hop_families([6, 10, 15]) == [(6, [6]), (10, [10]), (15, [15])]
+    for g, fam in hop_families([3, 6, 7, 14, 12, 28]):
+        assert all(h % g == 0 for h in fam) and 1.0 / g <= sum(1.0 / h for h in fam) + 1e-12
+
+
 def test_frame_shards_of_one_long_clip():
     """a single long recording is cut at frame boundaries; every frame has one owner and an owner's sample range
     holds exactly its frames (the halo of nperseg - hop samples is read by both neighbours)."""
@@ -342,6 +354,25 @@ GLOO_SCRIPT = textwrap.dedent('''
             assert np.array_equal(res_b[k], res[k]), k
     else:
         assert res_b is None
+    # hops that divide each other share one transform per n_fft (sweep.hop_families): 3 calls instead of 6, same values
+    calls2 = {"run": 0}
+    def open_family_batch(xs):
+        def run(n, h, a, b):
+            calls2["run"] += 1
+            f, t, s = orc.spectrogram(xs[a:b], fs=8000.0, nperseg=n, window="hann", noverlap=n - h)
+            return np.log10(s.sum(axis=-2) + 1e-20).astype(np.float32)
+        def family(n, g, members):
+            a0, b0 = min(m[1] for m in members), max(m[2] for m in members)
+            base = run(n, g, a0, b0)
+            return [base[a - a0:b - a0, ::h // g][:, :sd.n_frames(xs.shape[1], n, h)] for h, a, b in members]
+        run.family = family
+        return run
+    res_f = sweep.sharded_sweep(clips, 8000.0, [128, 256, 512], [32, 64], batch_compute=open_family_batch, dst=0)
+    assert calls2["run"] == 3
+    if rank == 0:
+        assert res_f.keys() == res.keys()
+        for k in res:
+            assert np.array_equal(res_f[k], res[k]), k
     dist.barrier(); dist.destroy_process_group()
     os.write(1, ("rank %d ok" % rank + chr(10)).encode())   # one write per rank: print() pieces of two ranks can interleave
 ''')

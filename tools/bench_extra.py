@@ -102,6 +102,30 @@ for n in (256, 512, 1024, 2048, 4096):
         p.close()
 res["cfg4_sweep_64clips"] = sweep
 res["cfg4_total_ms"] = sum(v["ms"] for v in sweep.values())
+# hops 64 / 128 / 256 of one n_fft share the hop-64 transform (frame i at hop h IS frame i*h/64 at hop 64: spectro.sweep.hop_families);
+# a consumer that takes the coarser hops as row subsets of the hop-64 spectrum pays 5 transforms instead of 15
+res["cfg4_total_shared_hops_ms"] = sum(v["ms"] for k, v in sweep.items() if k.endswith("_h64"))
+
+# the sweep's REDUCED product (what spectro.sweep.sharded_sweep moves: per-frame band power, fused -- no spectrum is written):
+# 15 fused launches, and the 5 launches hop sharing leaves
+band = {}
+d_bp = _capi.DeviceBuffer(n_clips * ((N - 256) // 64 + 1) * 4)
+for n in (256, 512, 1024, 2048, 4096):
+    for hop in (64, 128, 256):
+        p = _capi.Plan(n, n, hop, get_window("hann", n), 1, 48000.0, 0, 0, _capi.F32)
+        nf = p.n_frames(N)
+        turn = [0]
+
+        def step():
+            turn[0] += 1
+            p.band_power(ins[turn[0] % NB].ptr, N, N, n_clips, 1, n // 4, d_bp.ptr, nf)
+        t = timed(step, iters=max(8, int(0.05 / max(1e-5, 1e-9 * n_clips * nf * (n / 256)))), warm=4, settle_s=0.25)
+        band[f"n{n}_h{hop}"] = {"kernel": p.kernel, "frames": n_clips * nf, "ms": t * 1e3, "frames_per_s": n_clips * nf / t}
+        p.close()
+d_bp.free()
+res["cfg4_band_power_sweep_64clips"] = band
+res["cfg4_band_power_total_ms"] = sum(v["ms"] for v in band.values())
+res["cfg4_band_power_total_shared_hops_ms"] = sum(v["ms"] for k, v in band.items() if k.endswith("_h64"))
 
 # ---- cfg5: streaming 8 ch x 96 kHz, n_fft 4096 hop 1024, 4096-sample chunks ----
 st = StreamingSTFT(8, 96000.0, 4096, 1024, window="hann")
