@@ -236,6 +236,21 @@ def test_fused_band_power_every_f32_family(sp, nperseg, hop, family):
         plan.force_kernel(restore)
 
 
+@pytest.mark.parametrize("dt", ["float32", "float64"])
+@pytest.mark.parametrize("nperseg", [256, 512, 1024, 2048, 4096, 1000])
+def test_coarser_hops_are_row_subsets_of_the_finest(sp, dt, nperseg):
+    """Frame i at hop h is frame i*h/g at hop g (same samples, same arithmetic): what sweep.hop_families relies on, for every
+    kernel family -- including the r8x3 variants that slide their window in registers at some hops and reload at others."""
+    rng = np.random.default_rng(nperseg)
+    x = (rng.standard_normal((3, nperseg + 64 * 57 + 10)) * 0.3 + 0.2).astype(dt)
+    kw = dict(fs=48000.0, nperseg=nperseg, window="hann")
+    _, t64, s64 = sp.spectrogram(x, noverlap=nperseg - 64, **kw)
+    for hop in (128, 256, 192):
+        _, t, s = sp.spectrogram(x, noverlap=nperseg - hop, **kw)
+        np.testing.assert_array_equal(s, s64[..., ::hop // 64][..., :s.shape[-1]])
+        np.testing.assert_array_equal(t, t64[::hop // 64][:t.size])
+
+
 def test_full_size_properties(sp):
     """BASELINE cfg2 at full size (64 x 480000): size-independent properties.
 
