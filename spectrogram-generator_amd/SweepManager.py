@@ -147,26 +147,42 @@ class SweepManager:
         from spectro import spectrogram
         return spectrogram(x, fs=fs, nperseg=nperseg, **kw)
 
-    def parameter_sweep(self, names, n_ffts, hops, processed=False, window="hann", reduce=None):
+    def parameter_sweep(self, names, n_ffts, hops, processed=False, window="hann", reduce=None, share_hops=True):
         """BASELINE cfg4: every (n_fft, hop) pair over the named clips.
 
         Returns ``{(n_fft, hop): (f, t, result)}``; ``reduce`` maps a ``DeviceSpectrogram`` to what should be
-        copied back (default: the full ``[clip, freq, time]`` PSD)."""
-        from spectro import engine
+        copied back (default: the full ``[clip, freq, time]`` PSD).
+
+        ``share_hops`` (default on, full-PSD form only): hops of one n_fft that divide each other are served by ONE transform
+        and ONE download at their gcd (``spectro.sweep.hop_families``); the coarser hops come back as strided views
+        ``[..., ::h//g]`` of that array -- the same numbers bit for bit (frame i at hop h is frame i*h/g at hop g), 1 unit of
+        device work and PCIe traffic per n_fft instead of 1 + 1/2 + 1/4 for cfg4's hops.  Copy a result before writing to it."""
+        from spectro import _capi, engine
+        from spectro.dist import n_frames
+        from spectro.sweep import hop_families
         x, fs = self._stack(names, processed)
         clips = engine.DeviceClips(x)                  # the clips cross PCIe once for all pairs
         out = {}
         try:
             for n in n_ffts:
-                for h in hops:
-                    dev = clips.stft(fs=fs, window=window, nperseg=n, hop=h)
+                families = hop_families(hops) if (share_hops and reduce is None) else [(int(h), [int(h)]) for h in hops]
+                for g, fam in families:
+                    dev = clips.stft(fs=fs, window=window, nperseg=n, hop=g)
+                    nps = min(int(n), x.shape[-1])              # resolve_segments clamps nperseg to the clip length
                     try:
-                        out[(n, h)] = (dev.f, dev.t, dev.to_host() if reduce is None else reduce(dev))
+                        if reduce is not None:
+                            out[(n, g)] = (dev.f, dev.t, reduce(dev))
+                            continue
+                        full = dev.to_host()
+                        for h in fam:
+                            nfr = n_frames(x.shape[-1], nps, h)
+                            t = dev.t if h == g else _capi.times(x.shape[-1], nps, h, fs)
+                            out[(n, h)] = (dev.f, t, full if h == g else full[..., ::h // g][..., :nfr])
                     finally:
                         dev.free()
         finally:
             clips.free()
-        return out
+        return {(n, h): out[(n, int(h))] for n in n_ffts for h in hops}
 
 
 def read_wav(path):

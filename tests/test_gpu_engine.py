@@ -518,6 +518,17 @@ def test_sweepmanager_batch_pipeline_flag():
         fo, to, so = orc.spectrogram(np.stack([sm.data[k]["raw"] for k in names]), fs=8000.0, nperseg=n, window="hann", noverlap=n - h)
         np.testing.assert_array_equal(t, to)
         assert_spec_close(s, so, time_axis=-1)
+    # hop 256 came back as a strided view of the hop-64 download; the unshared sweep gives the same bits and owns its arrays
+    assert sweep[(256, 256)][2].base is not None and np.shares_memory(sweep[(256, 256)][2], sweep[(256, 64)][2])
+    plain = sm.parameter_sweep(names, [256, 1024], [64, 256, 96], share_hops=False)
+    shared = sm.parameter_sweep(names, [256, 1024], [64, 256, 96])
+    assert list(shared) == list(plain)
+    for k in plain:
+        for u, v in zip(plain[k], shared[k]):
+            np.testing.assert_array_equal(u, v)
+    assert not np.shares_memory(plain[(256, 256)][2], plain[(256, 64)][2])
+    red = sm.parameter_sweep(names, [256], [64, 128], reduce=lambda dev: dev.minmax(0, dev.n_bins - 1))
+    assert set(red) == {(256, 64), (256, 128)}
 
 
 def test_long_clip_cut_at_frame_boundaries_is_the_whole_call():
