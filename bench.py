@@ -68,6 +68,7 @@ def parse():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: every rank owns a --clips batch; strong: ONE --clips batch is sharded over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reference-mode", action="store_true", help="skip the untimed reference-mode (Tukey, hop 896; f32 and f64) leg")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline work")
     ap.add_argument("--kernel", default=None, help="force a kernel family (debug): r8x3 | stockham")
     ap.add_argument("--settle-ms", type=float, default=60.0,
@@ -262,6 +263,15 @@ def main():
         except Exception as e:                                    # sensors are a report, never a failure
             print(f"[bench] telemetry unavailable: {e}", file=sys.stderr)
 
+    # the reference's literal call (PlotEngine.py:113: Tukey(0.25), hop 896) on the same clips, f32 and -- what the reference's
+    # loaders hand over -- f64: reported beside cpu_baseline.reference_mode, never part of `value`
+    ref_mode = None
+    if rank == 0 and world == 1 and n_clips > 0 and not args.no_reference_mode:
+        try:
+            ref_mode = time_reference_mode(_capi, get_window, xs, n_clips, dev, stream)
+        except Exception as e:
+            print(f"[bench] reference-mode leg failed: {e}", file=sys.stderr)
+
     gather = None
     if world > 1 and not args.no_gather:
         gather = time_gather(args, plan, xs[0], outs[0], n_clips, n_frames, dev, same_gpu, world, rank, stream)
@@ -320,6 +330,8 @@ def main():
                               else "below the power cap")
             if power.get("board_W"):
                 res["power"]["uJ_per_frame"] = power["board_W"] * power["us_per_launch_during_sample"] / max(frames_per_step, 1)
+        if ref_mode:
+            res["reference_mode"] = ref_mode
         if gather:
             res["gather"] = gather
         if world == 1 and not args.no_cpu_baseline:
@@ -330,6 +342,49 @@ def main():
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def time_reference_mode(_capi, get_window, xs, n_clips, dev, stream, secs=0.4):
+    """spectrogram(x, fs, nperseg=1024, scaling='density', mode='psd') as the reference calls it (window ('tukey', .25),
+    noverlap = nperseg // 8 -> hop 896, detrend 'constant') on the bench's clips, f32 and f64, inputs resident; rotating buffer sets
+    as in the headline leg.  HIP events on the launch stream."""
+    import torch
+    hop = NPERSEG - NPERSEG // 8
+    out = {"call": "scipy.signal.spectrogram(x, fs, nperseg=1024, scaling='density', mode='psd') -> Tukey(0.25), hop 896, "
+                   "detrend constant (PlotEngine.py:113); untimed leg after the headline region, inputs resident in HBM"}
+    for name, tdt, code, isz in (("f32", torch.float32, _capi.F32, 4), ("f64", torch.float64, _capi.F64, 8)):
+        plan = _capi.Plan(NPERSEG, NPERSEG, hop, get_window(("tukey", 0.25), NPERSEG), _capi.DETREND["constant"], FS,
+                          _capi.SCALING["density"], _capi.MODE["psd"], code)
+        nfr = plan.n_frames(N_SAMPLES)
+        ins = xs if tdt == torch.float32 else [x.to(torch.float64) for x in xs[:2]]
+        outs = [torch.empty((n_clips, nfr, N_BINS), device=dev, dtype=tdt) for _ in range(len(ins))]
+
+        def step(i):
+            b = i % len(ins)
+            plan.stft(ins[b].data_ptr(), N_SAMPLES, N_SAMPLES, n_clips, outs[b].data_ptr(), nfr * N_BINS, stream=stream)
+        for i in range(20):
+            step(i)
+        torch.cuda.synchronize(dev)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n, t0 = 0, time.perf_counter()
+        ev0.record()
+        while time.perf_counter() - t0 < secs:
+            for _ in range(50):
+                step(n)
+                n += 1
+            torch.cuda.synchronize(dev)
+        ev1.record()
+        torch.cuda.synchronize(dev)
+        us = ev0.elapsed_time(ev1) * 1e3 / n
+        bpf = hop * isz + N_BINS * isz
+        out[name] = {"kernel": plan.kernel, "frames": n_clips * nfr, "us_per_launch": us, "frames_per_s": n_clips * nfr / us * 1e6,
+                     "algorithmic_bytes_per_frame": bpf, "achieved_GBs": n_clips * nfr * bpf / us / 1e3,
+                     "frac_of_hbm_peak": n_clips * nfr * bpf / us / 1e3 / HBM_PEAK_GBS, "buffer_sets": len(ins)}
+        plan.close()
+        del outs
+        if tdt != torch.float32:
+            del ins
+    return out
 
 
 def time_gather(args, plan, x, out, n_clips, n_frames, dev, same_gpu, world, rank, stream):
