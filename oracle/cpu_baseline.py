@@ -86,7 +86,9 @@ def time_cpu_baseline(clips: np.ndarray, fs: float, nperseg: int, hop: int, wind
     ref_hop = nperseg - nperseg // 8
     kw_ref = dict(fs=fs, nperseg=nperseg, scaling="density", mode="psd")
     n_frames_ref = ((clips.shape[1] - nperseg) // ref_hop + 1) * clips.shape[0]
-    r1, rn, rreps1, rrepsn = _time_mode(fn, clips, kw_ref, n_frames_ref, budget_s * 0.35, threads)
+    r1, rn, rreps1, rrepsn = _time_mode(fn, clips, kw_ref, n_frames_ref, budget_s * 0.25, threads)
+    # ... and on float64 clips, the dtype the reference's loaders hand over (SweepManager.py:135-136): scipy computes in it
+    d1, dn, _, dreps = _time_mode(fn, clips.astype(np.float64), kw_ref, n_frames_ref, budget_s * 0.10, threads)
     return {
         "value": vn, "unit": "frames/s", "cores": threads, "kind": kind,
         "single_thread_value": v1,
@@ -96,8 +98,9 @@ def time_cpu_baseline(clips: np.ndarray, fs: float, nperseg: int, hop: int, wind
                    f"host: {cpu_model()}, {os.cpu_count()} logical CPUs"),
         "reference_mode": {
             "value": rn, "single_thread_value": r1, "unit": "frames/s", "cores": threads, "frames": n_frames_ref,
+            "f64_value": dn, "f64_single_thread_value": d1,
             "sample": (f"the reference's literal call (PlotEngine.py:113): spectrogram(x, fs={fs:g}, nperseg={nperseg}, "
                        f"scaling='density', mode='psd') -> Tukey(0.25), hop {ref_hop}; same clips = {n_frames_ref} frames; "
-                       f"best of {rrepsn} (pool) / best of {rreps1} (1 thread)"),
+                       f"best of {rrepsn} (pool) / best of {rreps1} (1 thread); f64_value: the same call on float64 copies, best of {dreps}"),
         },
     }
