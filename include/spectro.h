@@ -143,6 +143,8 @@ int sg_stft_i16(const sg_plan* plan, const int16_t* x_dev, int64_t n_samples, in
  * Same framing/FFT but the spectrum never reaches HBM: per frame only
  * p[frame] = sum_{k in [k_lo, k_hi]} Sxx[k, frame] is written (A11 band sum,
  * PlotEngine.py:238-239).  band_out_dev: [n_clips][n_frames] of the plan's dtype.
+ * Needs a psd plan; fused in every register family (f32 256...4096, f64 256...1024) and in the LDS kernel;
+ * SG_ERR_UNSUPPORTED on a chirp-z ("bluestein") plan (use sg_stft + sg_band_sum there).
  */
 int sg_stft_band_power(const sg_plan* plan, const void* x_dev, int64_t n_samples,
                        int64_t clip_stride, int n_clips, int k_lo, int k_hi,
