@@ -86,7 +86,9 @@ struct R8Params {
     int64_t clip_stride;
     int n_frames;          // per clip
     int hop;
-    int64_t total_frames;  // n_frames * n_clips, flattened index g = clip * n_frames + f
+    int sub;               // hop * sub == 128 (hops 64, 32): a clip's frames are walked as `sub` interleaved sequences of hop 128
+                           // (frames v, v + sub, v + 2 sub, ...), each of which slides its window in registers; 1 otherwise
+    int64_t total_frames;  // n_frames * n_clips, flattened index g = clip * n_frames + j, j = position in that walk
     int n_waves;           // waves in the grid; wave w owns g in [w*total/n_waves, (w+1)*total/n_waves)
     float* out;            // [clip][frame][513] (OUT_PSD / OUT_MAG), [clip][frame] (OUT_BAND), [clip][frame][k_hi-k_lo+1] (OUT_DB*)
     int64_t out_clip_stride;
@@ -233,11 +235,24 @@ __global__ __launch_bounds__(64 * kWavesPerWg, occupancy_for(OUT)) void stft1024
         g += f1 - f0;
 
         const TIn* const xclip = static_cast<const TIn*>(p.x) + static_cast<int64_t>(clip) * p.clip_stride + 2 * lane;
+        // positions [f0, f1) of the clip's walk -> one stretch of one sequence: frames fs, fs + sub, ..., `count` of them
+        // (sub == 1: the frames f0 ... f1 - 1 themselves).  Sequence v holds ceil((n_frames - v) / sub) frames.
+        int fs = f0, count = f1 - f0;
+        if (p.sub > 1) {
+            int v = 0, first = 0, len = (p.n_frames + p.sub - 1) / p.sub;
+            while (f0 >= first + len) { first += len; ++v; len = (p.n_frames - v + p.sub - 1) / p.sub; }
+            fs = (f0 - first) * p.sub + v;
+            count = min(f1 - f0, first + len - f0);
+            g -= (f1 - f0) - count;                         // the rest of [f0, f1) belongs to the next sequence: next trip
+        }
+        const int fstep = p.sub;
         // (OUT_DB_BAND: orow[k] is bin k's slot, i.e. the row start minus k_lo)
-        float* orow = BAND ? p.out + static_cast<int64_t>(clip) * p.out_clip_stride + f0
-                           : p.out + static_cast<int64_t>(clip) * p.out_clip_stride + static_cast<int64_t>(f0) * row_len -
+        float* orow = BAND ? p.out + static_cast<int64_t>(clip) * p.out_clip_stride + fs
+                           : p.out + static_cast<int64_t>(clip) * p.out_clip_stride + static_cast<int64_t>(fs) * row_len -
                                  (OUT == OUT_DB_BAND ? p.k_lo : 0);
-        const TIn* src = xclip + static_cast<int64_t>(f0) * p.hop;
+        const int row_step = (BAND ? 1 : row_len) * fstep;
+        const int src_step = p.hop * fstep;
+        const TIn* src = xclip + static_cast<int64_t>(fs) * p.hop;
 
         float2 raw[8];
 #pragma unroll
@@ -348,7 +363,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg, occupancy_for(OUT)) void stft1024
             if (BAND) {
                 const float tot = wave_sum(band);
                 if (lane == 0) *orow = tot;
-                orow += 1;
+                orow += row_step;
             } else if (MEL) {
                 wave_lds_fence();                                  // the row is complete
 #pragma unroll
@@ -367,9 +382,9 @@ __global__ __launch_bounds__(64 * kWavesPerWg, occupancy_for(OUT)) void stft1024
                     if (p.log_scale) v = 3.01029995663981195f * __log2f(fmaxf(v, 1e-10f));      // 10 log10 through v_log_f32
                     if (lane + 64 * q < p.n_mels) orow[lane + 64 * q] = v;
                 }
-                orow += row_len;
+                orow += row_step;
             } else {
-                orow += row_len;
+                orow += row_step;
             }
             wave_lds_fence();    // next frame's exchange-1 writes stay behind these reads
         };
@@ -380,13 +395,13 @@ __global__ __launch_bounds__(64 * kWavesPerWg, occupancy_for(OUT)) void stft1024
         //  8 / gcd(8, H) rotations, no v_mov -- measured twice: round 1 83.6-84.7 vs 84.3-85.1 us at 142 VGPRs, round 2
         //  97.8 us at 144 VGPRs / 3 waves per SIMD and 119.7 us with the spills of 128 VGPRs against 89.2 us rolled;
         //  profiles/r02_ab_rotation.txt)
-        for (int f = f0; f < f1; ++f) {
+        for (int i = 0; i < count; ++i) {
             float2 a[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) a[k] = raw[k];
             prep(a);
-            src += p.hop;
-            if (f + 1 < f1) {      // prefetch frame f+1 (wave-uniform branch)
+            src += src_step;
+            if (i + 1 < count) {   // prefetch the stretch's next frame (wave-uniform branch)
                 if (H > 0) {
 #pragma unroll
                     for (int k = 0; k + H < 8; ++k) raw[k] = raw[k + H];
@@ -421,7 +436,7 @@ int launch_h(const R8Params& prm, int n_wg, hipStream_t stream) {
 template <typename TIn, bool ALIGNED, bool DETREND, int OUT>
 int launch_one(const R8Params& prm, int n_wg, hipStream_t stream) {
     if constexpr (std::is_same<TIn, float>::value && ALIGNED) {
-        switch (prm.hop) {
+        switch (prm.hop * prm.sub) {
             case 128: return launch_h<TIn, ALIGNED, DETREND, OUT, 1>(prm, n_wg, stream);
             case 256: return launch_h<TIn, ALIGNED, DETREND, OUT, 2>(prm, n_wg, stream);
             case 512: return launch_h<TIn, ALIGNED, DETREND, OUT, 4>(prm, n_wg, stream);
@@ -488,6 +503,7 @@ int launch_r8x3(const sg_plan& p, const StftArgs& a) {
     prm.clip_stride = a.clip_stride;
     prm.n_frames = static_cast<int>(a.n_frames);
     prm.hop = p.hop;
+    prm.sub = 1;
     prm.total_frames = a.n_frames * a.n_clips;
     prm.n_waves = r8x3_grid_waves(p, prm.total_frames, a.mel_ipl > 0);
     const int n_wg = (prm.n_waves + kWavesPerWg - 1) / kWavesPerWg;
@@ -520,6 +536,9 @@ int launch_r8x3(const sg_plan& p, const StftArgs& a) {
         return launch_in<int16_t>(prm, n_wg, a.stream, aligned, detrend, out);
     }
     const bool aligned = (p.hop % 2 == 0) && (a.clip_stride % 2 == 0) && (reinterpret_cast<uintptr_t>(a.x) % 8 == 0);
+    // hops 64 and 32: two / four interleaved hop-128 sequences, so the window slides in registers (one 8-byte load per lane and
+    // frame instead of eight); rows of one sequence are 2 / 4 rows apart in the output
+    if (aligned && a.mel_ipl == 0 && (p.hop == 64 || p.hop == 32) && !getenv("SPECTRO_R8_NO_SUB")) prm.sub = 128 / p.hop;
     if (a.mel_ipl > 0 && !aligned) { set_error("r8x3: the mel form needs an even hop / clip stride and 8-byte aligned input"); return SG_ERR_UNSUPPORTED; }
     return launch_in<float>(prm, n_wg, a.stream, aligned, detrend, out);
 }
