@@ -536,9 +536,9 @@ int launch_r8x3(const sg_plan& p, const StftArgs& a) {
         return launch_in<int16_t>(prm, n_wg, a.stream, aligned, detrend, out);
     }
     const bool aligned = (p.hop % 2 == 0) && (a.clip_stride % 2 == 0) && (reinterpret_cast<uintptr_t>(a.x) % 8 == 0);
-    // hops 64 and 32: two / four interleaved hop-128 sequences, so the window slides in registers (one 8-byte load per lane and
-    // frame instead of eight); rows of one sequence are 2 / 4 rows apart in the output
-    if (aligned && a.mel_ipl == 0 && (p.hop == 64 || p.hop == 32) && !getenv("SPECTRO_R8_NO_SUB")) prm.sub = 128 / p.hop;
+    // hops 64, 32, 16: two / four / eight interleaved hop-128 sequences, so the window slides in registers (one 8-byte load per
+    // lane and frame instead of eight); rows of one sequence are 2 / 4 / 8 rows apart in the output
+    if (aligned && a.mel_ipl == 0 && (p.hop == 64 || p.hop == 32 || p.hop == 16) && !getenv("SPECTRO_R8_NO_SUB")) prm.sub = 128 / p.hop;
     if (a.mel_ipl > 0 && !aligned) { set_error("r8x3: the mel form needs an even hop / clip stride and 8-byte aligned input"); return SG_ERR_UNSUPPORTED; }
     return launch_in<float>(prm, n_wg, a.stream, aligned, detrend, out);
 }

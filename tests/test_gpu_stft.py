@@ -103,15 +103,15 @@ def test_r8x3_variants(sp, hop, detrend, mode):
     assert_spec_close(s, so, time_axis=-1)
 
 
-@pytest.mark.parametrize("hop", [64, 32])
+@pytest.mark.parametrize("hop", [64, 32, 16])
 def test_r8x3_interleaved_sequences_at_small_hops(sp, hop):
-    """hops 64 / 32 walk a clip as 2 / 4 interleaved hop-128 sequences (register sliding window): every frame count from one
+    """hops 64 / 32 / 16 walk a clip as 2 / 4 / 8 interleaved hop-128 sequences (register sliding window): every frame count from one
     frame up, several clips, spectrum + fused band power + fused dB image against the oracle / the unfused composition."""
     from spectro import _capi, engine
     from spectro.signal import plan_for
     from spectro.windows import get_window
     rng = np.random.default_rng(hop)
-    for n_frames in (1, 2, 3, 4, 5, 7, 38, 77, 301):
+    for n_frames in (1, 2, 3, 4, 5, 7, 8, 9, 17, 38, 77, 301):
         n = 1024 + hop * (n_frames - 1) + 6
         x = (rng.standard_normal((3, n)) * 0.3 + 0.4).astype(np.float32)
         kw = dict(fs=48000.0, nperseg=1024, window="hann", noverlap=1024 - hop)
