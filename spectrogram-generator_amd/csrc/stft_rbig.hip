@@ -12,6 +12,10 @@
 // Every exchange moves 8 registers per lane at a time through ONE 4.5 KiB slab per wave (a wave's DS operations
 // execute in issue order, so the slab is reused back to back without waiting): 12 (T = 4) / 16 (T = 2) waves per CU
 // instead of the 6 a whole-frame slab allowed -- the kernel was latency-bound at 1.5 waves per SIMD.
+// Round 2: at hops 128 / 256 (and 64 / 32 / 16 walked as interleaved hop-128 sequences, stft_r8x3.hip) the frame's samples stay in
+// registers and slide by one or two 128-sample blocks per frame: one or two 8-byte loads per lane and frame instead of 8T from
+// L1 / L2 -- a reloaded sample costs about what an HBM byte costs on this part (nfft 2048: -25...30 %; nfft 4096, at 2 waves per
+// SIMD for the 64 extra VGPRs: -13...16 %).  The fused band power (A11) is one more output form.
 // Algorithmic HBM bytes per frame: hop*4 + (512T+1)*4.
 #include "spectro_internal.h"
 #include "fft_wave.h"
@@ -33,13 +37,17 @@ constexpr int kS1 = 72, kS2 = 66;
 #ifndef SG_RBIG4_OCC
 #define SG_RBIG4_OCC 3            // waves per SIMD the T = 4 kernel is compiled for
 #endif
-template <int T> struct WavesFor { static constexpr int value = T == 4 ? 4 * SG_RBIG4_OCC : 8; };
+// H > 0 (the sample window slides in registers, see the frame loop): T = 4 keeps 32 more float2 per lane -> 2 waves per SIMD
+template <int T, int H> struct OccFor { static constexpr int value = T == 4 ? (H > 0 ? 2 : SG_RBIG4_OCC) : 4; };
+template <int T, int H> struct WavesFor { static constexpr int value = T == 4 ? 4 * OccFor<T, H>::value : 8; };
 constexpr int kSlabElems = 8 * kS1;                          // one 8-register exchange group (576 float2)
 
 struct BigParams {
     const float* x;
     int64_t clip_stride;
     int n_frames, hop;
+    int sub;                  // hop * sub is a multiple of 128 (H > 0): a clip's frames are walked as `sub` interleaved sequences
+                              // (frames v, v + sub, ...) whose window slides in registers (stft_r8x3.hip); 1 otherwise
     int64_t total_frames;
     int n_waves;
     float* out;
@@ -70,9 +78,10 @@ template <int R> __device__ __forceinline__ float2 const_tw(int n) {
     return R == 16 ? make_float2(kW16[n & 15][0], kW16[n & 15][1]) : make_float2(kW32[n & 31][0], kW32[n & 31][1]);
 }
 
-template <int T, bool DETREND, int MODE>
-__global__ __launch_bounds__(64 * WavesFor<T>::value, T == 4 ? SG_RBIG4_OCC : 4) void stft_rbig_kernel(const BigParams p) {
-    constexpr int R = 8 * T, M = 64 * R, NB = M + 1, kWaves = WavesFor<T>::value;
+// H: hop * sub == 128 * H and the sample window slides in registers (H blocks of 128 samples per frame); 0: every frame reloads
+template <int T, bool DETREND, int MODE, int H>
+__global__ __launch_bounds__((64 * WavesFor<T, H>::value), (OccFor<T, H>::value)) void stft_rbig_kernel(const BigParams p) {
+    constexpr int R = 8 * T, M = 64 * R, NB = M + 1, kWaves = WavesFor<T, H>::value;
     constexpr int kSlab = kSlabElems;                        // complex elements per wave
     constexpr int kTw1 = M, kTw2 = kTw1 + (R - 1) * 64, kTw3 = kTw2 + 7 * 64, kTabs = kTw3 + (R / 2) * 64;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
@@ -108,40 +117,9 @@ __global__ __launch_bounds__(64 * WavesFor<T>::value, T == 4 ? SG_RBIG4_OCC : 4)
 
     const float r0 = (MODE != 1 && lane == 0) ? 0.5f : 1.0f;
 
-    // T = 2 fetches the samples of frame g+1 at the top of frame g (+32 VGPRs throughout).  T = 4 has no registers to
-    // spare and loads at the top of the frame; fetching late, as the split pass frees registers, or whole frames ahead at
-    // 2 waves/SIMD, measured slower (1.83-2.26 ms against 1.78 ms per 64-clip batch at hop 64).
-    constexpr bool kPrefetch = T == 2;
-    auto load_frame = [&](int clip, int f, float2 (&dst)[T][8]) {
-        const float* const src = p.x + static_cast<int64_t>(clip) * p.clip_stride + static_cast<int64_t>(f) * p.hop + 2 * lane;
-#pragma unroll
-        for (int a0 = 0; a0 < T; ++a0)
-#pragma unroll
-            for (int a1 = 0; a1 < 8; ++a1) dst[a0][a1] = *reinterpret_cast<const float2*>(src + 128 * (a0 + T * a1));
-    };
-    // (clip, frame) of the run's first frame by one division; after that they advance incrementally
-    int clip = static_cast<int>(g / p.n_frames);
-    int f = static_cast<int>(g - static_cast<int64_t>(clip) * p.n_frames);
-    float2 nxt[kPrefetch ? T : 1][8];
-    if (kPrefetch && g < g_end) load_frame(clip, f, reinterpret_cast<float2 (&)[T][8]>(nxt));
-
-    for (; g < g_end; ++g) {
-        float* const orow = p.out + static_cast<int64_t>(clip) * p.out_clip_stride + static_cast<int64_t>(f) * (MODE == 2 ? 1 : NB);
+    // one frame: samples d[][] (destroyed) -> row orow
+    auto frame = [&](float2 (&d)[T][8], float* const orow) {
         float bsum = 0.f;                                    // MODE 2: this lane's share of the band sum (A11)
-        const int clip_n = f + 1 == p.n_frames ? clip + 1 : clip, f_n = f + 1 == p.n_frames ? 0 : f + 1;
-
-        float2 d[T][8];
-        if (kPrefetch) {
-#pragma unroll
-            for (int a0 = 0; a0 < T; ++a0)
-#pragma unroll
-                for (int a1 = 0; a1 < 8; ++a1) d[a0][a1] = nxt[kPrefetch ? a0 : 0][a1];
-            // the run's last frame fetches itself again: an unconditional fetch keeps the old registers out of the loop's live set
-            const bool more = g + 1 < g_end;
-            load_frame(more ? clip_n : clip, more ? f_n : f, reinterpret_cast<float2 (&)[T][8]>(nxt));
-        } else {
-            load_frame(clip, f, d);
-        }
         if (DETREND) {
             float s = d[0][0].x + d[0][0].y;
 #pragma unroll
@@ -261,8 +239,6 @@ __global__ __launch_bounds__(64 * WavesFor<T>::value, T == 4 ? SG_RBIG4_OCC : 4)
             }
             wave_lds_fence();
         }
-        clip = clip_n;
-        f = f_n;
         {   // k = M/2: lane 0, block c = R/2
             const float zx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, SG_Z(R / 2).x), 0));
             const float zy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, SG_Z(R / 2).y), 0));
@@ -277,47 +253,153 @@ __global__ __launch_bounds__(64 * WavesFor<T>::value, T == 4 ? SG_RBIG4_OCC : 4)
             }
         }
 #undef SG_Z
+    };
+
+    if constexpr (H == 0) {
+        // Every frame reloads its samples.  T = 2 fetches the samples of frame g+1 at the top of frame g (+32 VGPRs throughout);
+        // T = 4 has no registers to spare and loads at the top of the frame (fetching late, as the split pass frees registers,
+        // or whole frames ahead at 2 waves/SIMD, measured slower: 1.83-2.26 ms against 1.78 ms per 64-clip batch at hop 64).
+        constexpr bool kPrefetch = T == 2;
+        auto load_frame = [&](int clip, int f, float2 (&dst)[T][8]) {
+            const float* const src = p.x + static_cast<int64_t>(clip) * p.clip_stride + static_cast<int64_t>(f) * p.hop + 2 * lane;
+#pragma unroll
+            for (int a0 = 0; a0 < T; ++a0)
+#pragma unroll
+                for (int a1 = 0; a1 < 8; ++a1) dst[a0][a1] = *reinterpret_cast<const float2*>(src + 128 * (a0 + T * a1));
+        };
+        // (clip, frame) of the run's first frame by one division; after that they advance incrementally
+        int clip = static_cast<int>(g / p.n_frames);
+        int f = static_cast<int>(g - static_cast<int64_t>(clip) * p.n_frames);
+        float2 nxt[kPrefetch ? T : 1][8];
+        if (kPrefetch && g < g_end) load_frame(clip, f, reinterpret_cast<float2 (&)[T][8]>(nxt));
+
+        for (; g < g_end; ++g) {
+            float* const orow = p.out + static_cast<int64_t>(clip) * p.out_clip_stride + static_cast<int64_t>(f) * (MODE == 2 ? 1 : NB);
+            const int clip_n = f + 1 == p.n_frames ? clip + 1 : clip, f_n = f + 1 == p.n_frames ? 0 : f + 1;
+
+            float2 d[T][8];
+            if (kPrefetch) {
+#pragma unroll
+                for (int a0 = 0; a0 < T; ++a0)
+#pragma unroll
+                    for (int a1 = 0; a1 < 8; ++a1) d[a0][a1] = nxt[kPrefetch ? a0 : 0][a1];
+                // the run's last frame fetches itself again: an unconditional fetch keeps the old registers out of the loop's live set
+                const bool more = g + 1 < g_end;
+                load_frame(more ? clip_n : clip, more ? f_n : f, reinterpret_cast<float2 (&)[T][8]>(nxt));
+            } else {
+                load_frame(clip, f, d);
+            }
+            frame(d, orow);
+            clip = clip_n;
+            f = f_n;
+        }
+    } else {
+        // The frame's samples live in raw[][] across frames; the next frame shifts them by H blocks of 128 samples (register moves)
+        // and loads the H new blocks -- one or two 8-byte loads per lane and frame instead of 8T from L2 (measured on r8x3: a
+        // reloaded sample costs about what an HBM byte costs).  T = 4 pays 64 more VGPRs for it: 2 waves per SIMD (OccFor).
+        // blocks k >= first of the frame that starts `off` samples into the clip at xclip (both wave-uniform: the per-lane part of
+        // the address is the 32-bit 2*lane only)
+        auto load_blocks = [&](const float* xclip, int64_t off, float2 (&dst)[T][8], int first) {
+            const float* const src = xclip + off + 2 * lane;
+#pragma unroll
+            for (int k = 0; k < R; ++k)
+                if (k >= first) dst[k % T][k / T] = *reinterpret_cast<const float2*>(src + 128 * k);
+        };
+        while (g < g_end) {                                  // one trip per stretch: frames fs, fs + sub, ... (`count` of them) of one clip
+            const int clip = static_cast<int>(g / p.n_frames);
+            const int f0 = static_cast<int>(g - static_cast<int64_t>(clip) * p.n_frames);
+            const int f1 = static_cast<int>(min(static_cast<int64_t>(p.n_frames), f0 + (g_end - g)));
+            int fs = f0, count = f1 - f0;
+            if (p.sub > 1) {                                 // sequence v holds ceil((n_frames - v) / sub) frames (stft_r8x3.hip)
+                int v = 0, first = 0, len = (p.n_frames + p.sub - 1) / p.sub;
+                while (f0 >= first + len) { first += len; ++v; len = (p.n_frames - v + p.sub - 1) / p.sub; }
+                fs = (f0 - first) * p.sub + v;
+                count = min(f1 - f0, first + len - f0);
+            }
+            g += count;
+            const float* const xclip = p.x + static_cast<int64_t>(clip) * p.clip_stride;
+            int64_t soff = static_cast<int64_t>(fs) * p.hop;
+            float* orow = p.out + static_cast<int64_t>(clip) * p.out_clip_stride + static_cast<int64_t>(fs) * (MODE == 2 ? 1 : NB);
+            const int row_step = (MODE == 2 ? 1 : NB) * p.sub, src_step = p.hop * p.sub;
+            float2 raw[T][8];
+            load_blocks(xclip, soff, raw, 0);
+            for (int i = 0; i < count; ++i) {
+                float2 d[T][8];
+#pragma unroll
+                for (int a0 = 0; a0 < T; ++a0)
+#pragma unroll
+                    for (int a1 = 0; a1 < 8; ++a1) d[a0][a1] = raw[a0][a1];
+                soff += src_step;
+                if (i + 1 < count) {                         // wave-uniform
+#pragma unroll
+                    for (int k = 0; k + H < R; ++k) raw[k % T][k / T] = raw[(k + H) % T][(k + H) / T];
+                    load_blocks(xclip, soff, raw, R - H);
+                }
+                frame(d, orow);
+                orow += row_step;
+            }
+        }
     }
 }
 
-template <int T, bool DETREND>
-int launch_td(const BigParams& prm, int n_wg, size_t lds, hipStream_t s, int mode, bool band) {
-    constexpr int kWaves = WavesFor<T>::value;
-    auto k0 = stft_rbig_kernel<T, DETREND, 0>;
-    auto k1 = stft_rbig_kernel<T, DETREND, 1>;
-    auto k2 = stft_rbig_kernel<T, DETREND, 2>;
+template <int T, bool DETREND, int H>
+int launch_tdh(const BigParams& prm, hipStream_t s, int mode, bool band, int n_cu) {
+    constexpr int R = 8 * T, M = 64 * R, kWaves = WavesFor<T, H>::value;
+    auto k0 = stft_rbig_kernel<T, DETREND, 0, H>;
+    auto k1 = stft_rbig_kernel<T, DETREND, 1, H>;
+    auto k2 = stft_rbig_kernel<T, DETREND, 2, H>;
     auto kern = band ? k2 : mode == SG_MODE_PSD ? k0 : k1;
+    const size_t lds = (static_cast<size_t>(M) + (R - 1 + 7 + R / 2) * 64 + static_cast<size_t>(kWaves) * kSlabElems) * sizeof(float2);
+    const int wg_per_cu = static_cast<int>((160 * 1024) / lds) < 1 ? 1 : static_cast<int>((160 * 1024) / lds);
+    BigParams p = prm;
+    int64_t n_waves = static_cast<int64_t>(n_cu) * wg_per_cu * kWaves;
+    if (n_waves > p.total_frames) n_waves = p.total_frames;
+    p.n_waves = static_cast<int>(n_waves);
+    const int n_wg = static_cast<int>((n_waves + kWaves - 1) / kWaves);
     if (lds > 64 * 1024)
         SG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    hipLaunchKernelGGL(kern, dim3(n_wg), dim3(64 * kWaves), lds, s, prm);
+    hipLaunchKernelGGL(kern, dim3(n_wg), dim3(64 * kWaves), lds, s, p);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? SG_OK : hip_fail(e, "stft_rbig launch");
 }
 
+template <int T, bool DETREND>
+int launch_td(const BigParams& prm, hipStream_t s, int mode, bool band, int n_cu, int h) {
+    switch (h) {
+        case 1: return launch_tdh<T, DETREND, 1>(prm, s, mode, band, n_cu);
+        case 2: return launch_tdh<T, DETREND, 2>(prm, s, mode, band, n_cu);
+        default: return launch_tdh<T, DETREND, 0>(prm, s, mode, band, n_cu);
+    }
+}
+
 template <int T>
 int launch_t(const sg_plan& p, const StftArgs& a) {
-    constexpr int R = 8 * T, M = 64 * R, kWaves = WavesFor<T>::value;
     BigParams prm{};
     prm.x = static_cast<const float*>(a.x);
     prm.clip_stride = a.clip_stride;
     prm.n_frames = static_cast<int>(a.n_frames);
     prm.hop = p.hop;
+    prm.sub = 1;
     prm.total_frames = a.n_frames * a.n_clips;
-    const size_t lds = (static_cast<size_t>(M) + (R - 1 + 7 + R / 2) * 64 + static_cast<size_t>(kWaves) * kSlabElems) * sizeof(float2);
-    const int wg_per_cu = static_cast<int>((160 * 1024) / lds) < 1 ? 1 : static_cast<int>((160 * 1024) / lds);
-    int64_t n_waves = static_cast<int64_t>(p.n_cu) * wg_per_cu * kWaves;
-    if (n_waves > prm.total_frames) n_waves = prm.total_frames;
-    prm.n_waves = static_cast<int>(n_waves);
     prm.out = static_cast<float*>(a.out);
     prm.out_clip_stride = a.out_clip_stride;
     prm.win2 = static_cast<const float2*>(p.win_dev);
     prm.tw = static_cast<const float2*>(p.r8_tw_dev);
     prm.scale = static_cast<float>(p.scale);
     prm.k_lo = a.k_lo; prm.k_hi = a.k_hi;
-    const int n_wg = static_cast<int>((n_waves + kWaves - 1) / kWaves);
+    // sliding window: hops 128 and 256 directly, hops 64 / 32 / 16 as 2 / 4 / 8 interleaved hop-128 sequences
+    int h = 0;
+    const char* off = getenv("SPECTRO_RBIG_NO_SLIDE");      // A/B aid: "1" = never slide, "4" = not for T = 4
+    if (!(off && (off[0] == '1' || (off[0] == '4' && T == 4)))) {
+        if (p.hop == 128 || p.hop == 256) h = p.hop / 128;
+        else if (p.hop == 64 || p.hop == 32 || p.hop == 16) { h = 1; prm.sub = 128 / p.hop; }
+    }
     const bool band = a.band_mode != 0;                    // run_stft has checked: psd plan, 0 <= k_lo <= k_hi < n_bins
-    return p.detrend == SG_DETREND_CONSTANT ? launch_td<T, true>(prm, n_wg, lds, a.stream, p.mode, band)
-                                            : launch_td<T, false>(prm, n_wg, lds, a.stream, p.mode, band);
+    // T = 4 slides at 2 waves/SIMD (64 more VGPRs): -13...16 % with the rows written, +4 % for the band sums alone (no stores to
+    // hide behind; 1.34 against 1.29 ms per 64-clip batch at hop 64) -- the band form keeps reloading
+    if (T == 4 && band) { h = 0; prm.sub = 1; }
+    return p.detrend == SG_DETREND_CONSTANT ? launch_td<T, true>(prm, a.stream, p.mode, band, p.n_cu, h)
+                                            : launch_td<T, false>(prm, a.stream, p.mode, band, p.n_cu, h);
 }
 
 }  // namespace

@@ -103,24 +103,26 @@ def test_r8x3_variants(sp, hop, detrend, mode):
     assert_spec_close(s, so, time_axis=-1)
 
 
-@pytest.mark.parametrize("hop", [64, 32, 16])
-def test_r8x3_interleaved_sequences_at_small_hops(sp, hop):
-    """hops 64 / 32 / 16 walk a clip as 2 / 4 / 8 interleaved hop-128 sequences (register sliding window): every frame count from one
-    frame up, several clips, spectrum + fused band power + fused dB image against the oracle / the unfused composition."""
+@pytest.mark.parametrize("nperseg,hop", [(1024, 64), (1024, 32), (1024, 16), (2048, 64), (2048, 128), (2048, 256), (2048, 32),
+                                         (4096, 64), (4096, 128), (4096, 256), (4096, 16)])
+def test_sliding_window_walks(sp, nperseg, hop):
+    """Register sliding windows: hops 128 / 256 directly, hops 64 / 32 / 16 as 2 / 4 / 8 interleaved hop-128 sequences (r8x3 and
+    rbig): every frame count from one frame up, several clips, spectrum + fused band power against the oracle / the written
+    spectrum; at 1024 also the fused dB image."""
     from spectro import _capi, engine
     from spectro.signal import plan_for
     from spectro.windows import get_window
-    rng = np.random.default_rng(hop)
+    rng = np.random.default_rng(hop + nperseg)
     for n_frames in (1, 2, 3, 4, 5, 7, 8, 9, 17, 38, 77, 301):
-        n = 1024 + hop * (n_frames - 1) + 6
-        x = (rng.standard_normal((3, n)) * 0.3 + 0.4).astype(np.float32)
-        kw = dict(fs=48000.0, nperseg=1024, window="hann", noverlap=1024 - hop)
+        n = nperseg + hop * (n_frames - 1) + 6
+        x = (rng.standard_normal((3, n)) * 0.3 + 0.05).astype(np.float32)      # (a large DC offset is test_r8x3_variants' business)
+        kw = dict(fs=48000.0, nperseg=nperseg, window="hann", noverlap=nperseg - hop)
         f, t, s = sp.spectrogram(x, **kw)
         fo, to, so = orc.spectrogram(x, **kw)
         assert s.shape[-1] == n_frames
         np.testing.assert_array_equal(t, to)
         assert_spec_close(s, so, time_axis=-1)
-        plan = plan_for(get_window("hann", 1024), 1024, 1024, hop, 1, 48000.0, 0, 0, _capi.F32)
+        plan = plan_for(get_window("hann", nperseg), nperseg, nperseg, hop, 1, 48000.0, 0, 0, _capi.F32)
         d_in, d_bp = _capi.DeviceBuffer(x.nbytes), _capi.DeviceBuffer(3 * n_frames * 4)
         d_in.upload(x)
         _capi.check(_capi.lib().sg_memset(C.c_void_p(d_bp.ptr), 0xFF, 3 * n_frames * 4, None))
@@ -131,8 +133,9 @@ def test_r8x3_interleaved_sequences_at_small_hops(sp, hop):
         ref = s[:, 5:301, :].astype(np.float64).sum(axis=1)
         assert np.all(np.abs(bp - ref) <= 2e-6 * s.astype(np.float64).sum(axis=1) + 1e-30)
         d_in.free(); d_bp.free()
-    # fused dB image on the interleaved walk == the composed path of another plan size is covered elsewhere; here: same image as
-    # the hop-128 rows of the hop-64 image
+    if nperseg != 1024:
+        return
+    # fused dB image on the interleaved walk: the same image as the hop-128 rows of it
     x = (rng.standard_normal((2, 1024 + 128 * 40)) * 0.2).astype(np.float32)
     dc = engine.DeviceClips(x)
     try:
