@@ -14,7 +14,9 @@
 //     (tools/sim_r8x3.py, sim_rsmall.py) instead of a new analysis for 16-byte accesses;
 //   * 8 values + 8 prefetched + window + twiddle doubles per lane: 208-233 VGPRs at R = 8, two waves per SIMD;
 //   * no register sliding window (every group reloads its samples from L1 / L2; the next group's loads are issued before this
-//     group's FFT); of the fused products of the f32 kernel only the band power (A11: the HMM feature path on f64 recordings,
+//     group's FFT).  A sliding variant (hops 128 / 256 / 512 and interleaved 64 / 32 / 16, as in stft_r8x3.hip) was built and measured
+//     in round 2: 202 / 864 / 443 us against 201 / 862 / 434 us per 64-clip batch at hops 256 / 64 / 128 -- the f64 arithmetic, not the
+//     re-read samples, is what this kernel's joules go to; not kept; of the fused products of the f32 kernel only the band power (A11: the HMM feature path on f64 recordings,
 //     `sg_stft_band_power`) is replicated here.
 // Algorithmic HBM bytes per frame: hop*8 + (nfft/2+1)*8 (band power: hop*8 + 8).
 #include "spectro_internal.h"

@@ -146,6 +146,34 @@ def test_sliding_window_walks(sp, nperseg, hop):
         dc.free()
 
 
+@pytest.mark.parametrize("hop", [64, 32, 16, 128, 256, 512])
+def test_register_f64_small_and_block_hops(sp, hop):
+    """The double-precision 1024 kernel at the hops where the f32 kernels slide their window: every frame count, band power."""
+    from spectro import _capi
+    from spectro.signal import plan_for
+    from spectro.windows import get_window
+    rng = np.random.default_rng(900 + hop)
+    for n_frames in (1, 2, 3, 4, 5, 7, 8, 9, 17, 38, 77, 150):
+        n = 1024 + hop * (n_frames - 1) + 6
+        x = rng.standard_normal((3, n)) * 0.3 + 0.7
+        kw = dict(fs=20000.0, nperseg=1024, window=("tukey", 0.25), noverlap=1024 - hop)
+        f, t, s = sp.spectrogram(x, **kw)
+        fo, to, so = orc.spectrogram(x, **kw)
+        assert s.shape[-1] == n_frames
+        np.testing.assert_array_equal(t, to)
+        _check(s, so, np.float64)
+        plan = plan_for(get_window(("tukey", 0.25), 1024), 1024, 1024, hop, 1, 20000.0, 0, 0, _capi.F64)
+        d_in, d_bp = _capi.DeviceBuffer(x.nbytes), _capi.DeviceBuffer(3 * n_frames * 8)
+        d_in.upload(x)
+        plan.band_power(d_in.ptr, n, n, 3, 5, 300, d_bp.ptr, n_frames)
+        bp = np.empty((3, n_frames))
+        d_bp.download(bp)
+        _capi.stream_sync()
+        ref = s[:, 5:301, :].sum(axis=1)
+        assert np.all(np.abs(bp - ref) <= 1e-12 * 296 * s.max(axis=1) + 1e-300)
+        d_in.free(); d_bp.free()
+
+
 def test_r8x3_int16_input(sp):
     rng = np.random.default_rng(5)
     x = (rng.standard_normal((2, 20000)) * 4000).astype(np.int16)
