@@ -36,8 +36,8 @@
 extern "C" {
 #endif
 
-#define SG_VERSION 101 /* 0.1.1: sg_stft_mel takes weights_n_bins; sg_stft_db, sg_db_rescale, sg_colormap_db,
-                          * sg_band_features_batch, sg_device_pci_bus_id added */
+#define SG_VERSION 102 /* 0.1.1: sg_stft_mel takes weights_n_bins; sg_stft_db, sg_db_rescale, sg_colormap_db,
+                          * sg_band_features_batch, sg_device_pci_bus_id added; 0.1.2: sg_convert_i16 */
 
 typedef enum sg_status {
     SG_OK = 0,
@@ -139,6 +139,10 @@ int sg_stft(const sg_plan* plan, const void* x_dev, int64_t n_samples, int64_t c
  * Samples are used as-is (no 1/32768 scaling), i.e. like numpy's int16 -> float cast. */
 int sg_stft_i16(const sg_plan* plan, const int16_t* x_dev, int64_t n_samples, int64_t clip_stride,
                 int n_clips, float* out_dev, int64_t out_clip_stride, void* stream);
+/* dst[i] = (float)src[i], i < n: int16 PCM to the f32 the plans compute in (exact).  sg_stft_i16 does this itself where a
+ * kernel has no int16 loads of its own (batches on nperseg 256 / 512 / 2048 / 4096: a stream-ordered workspace, then the
+ * float kernel); exported for callers that keep a converted copy across many calls (spectro.engine.DeviceClips). */
+int sg_convert_i16(const int16_t* src_dev, float* dst_dev, int64_t n, void* stream);
 /*
  * Same framing/FFT but the spectrum never reaches HBM: per frame only
  * p[frame] = sum_{k in [k_lo, k_hi]} Sxx[k, frame] is written (A11 band sum,

@@ -97,6 +97,53 @@ static void free_tables(sg_plan* p) {
     }
 }
 
+// int16 PCM -> float, exact (|v| <= 32768): the front end of the register kernels that have no int16 loads of their own
+__global__ __launch_bounds__(256) void convert_i16_kernel(const int16_t* __restrict__ src, float* __restrict__ dst, int64_t n) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
+    int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (((reinterpret_cast<uintptr_t>(src) & 7) | (reinterpret_cast<uintptr_t>(dst) & 15)) == 0) {
+        const short4* const s4 = reinterpret_cast<const short4*>(src);
+        float4* const d4 = reinterpret_cast<float4*>(dst);
+        for (int64_t j = i; j < n / 4; j += stride) {
+            const short4 v = s4[j];
+            d4[j] = make_float4(static_cast<float>(v.x), static_cast<float>(v.y), static_cast<float>(v.z), static_cast<float>(v.w));
+        }
+        for (int64_t j = (n / 4) * 4 + i; j < n; j += stride) dst[j] = static_cast<float>(src[j]);
+    } else {
+        for (; i < n; i += stride) dst[i] = static_cast<float>(src[i]);
+    }
+}
+
+static int convert_i16(const int16_t* src, float* dst, int64_t n, hipStream_t s) {
+    if (n <= 0) return SG_OK;
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(convert_i16_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, src, dst, n);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SG_OK : hip_fail(e, "convert_i16 launch");
+}
+
+static int run_stft(const sg_plan* plan, StftArgs& a);
+
+// rsmall / rbig batches of int16 PCM: convert once into a stream-ordered float workspace (same clip stride, so the register
+// kernel's alignment rules are unchanged) and run the float kernel -- ~10x the LDS kernel's rate.  Small calls (a GUI sweep)
+// keep the LDS kernel's own int16 loads: the workspace allocation would cost more than it saves.
+static int run_converted(const sg_plan* plan, StftArgs& a) {
+    const int64_t span = static_cast<int64_t>(a.n_clips - 1) * a.clip_stride + a.n_samples;
+    void* work = nullptr;
+    SG_HIP(hipMallocAsync(&work, static_cast<size_t>(span) * sizeof(float), a.stream));
+    int rc = convert_i16(static_cast<const int16_t*>(a.x), static_cast<float*>(work), span, a.stream);
+    if (rc == SG_OK) {
+        StftArgs f = a;
+        f.x = work;
+        f.in_i16 = 0;
+        rc = run_stft(plan, f);
+    }
+    (void)hipFreeAsync(work, a.stream);
+    return rc;
+}
+
 static int run_stft(const sg_plan* plan, StftArgs& a) {
     if (!plan) { set_error("null plan"); return SG_ERR_ARG; }
     if (a.n_clips < 0 || a.n_samples < 0) { set_error("negative sizes"); return SG_ERR_ARG; }
@@ -111,6 +158,9 @@ static int run_stft(const sg_plan* plan, StftArgs& a) {
         if (plan->mode != SG_MODE_PSD) { set_error("band power needs a psd plan"); return SG_ERR_ARG; }
         if (a.k_lo < 0 || a.k_hi >= nbins || a.k_lo > a.k_hi) { set_error("bad band [%d,%d] of %d bins", a.k_lo, a.k_hi, nbins); return SG_ERR_ARG; }
     }
+    if (a.in_i16 && (plan->kernel == Kernel::RSMALL || plan->kernel == Kernel::RBIG) && plan->hop % 2 == 0 &&
+        (a.clip_stride % 2 == 0 || a.n_clips == 1) && static_cast<int64_t>(a.n_clips) * a.n_samples >= (1 << 18))
+        return run_converted(plan, a);
     switch (plan->kernel) {
         case Kernel::R8X3: return launch_r8x3(*plan, a);
         case Kernel::R8X3D: return r8x3_f64_can_run(*plan, a) ? launch_r8x3_f64(*plan, a) : launch_stockham(*plan, a);
@@ -361,6 +411,11 @@ int sg_stft_i16(const sg_plan* plan, const int16_t* x_dev, int64_t n_samples, in
     a.x = x_dev; a.in_i16 = 1; a.n_samples = n_samples; a.clip_stride = clip_stride; a.n_clips = n_clips;
     a.out = out_dev; a.out_clip_stride = out_clip_stride; a.stream = static_cast<hipStream_t>(stream);
     return run_stft(plan, a);
+}
+
+int sg_convert_i16(const int16_t* src_dev, float* dst_dev, int64_t n, void* stream) {
+    if (n < 0 || (n > 0 && (!src_dev || !dst_dev))) { set_error("sg_convert_i16: bad arguments"); return SG_ERR_ARG; }
+    return convert_i16(src_dev, dst_dev, n, static_cast<hipStream_t>(stream));
 }
 
 int sg_stft_band_power(const sg_plan* plan, const void* x_dev, int64_t n_samples, int64_t clip_stride, int n_clips,

@@ -340,17 +340,14 @@ class DeviceClips:
                         self.code), nperseg, int(hop), nfft
 
     def _float_ptr(self):
-        """device pointer of the clips as the plan's float type (int16 batches: converted once, on the host side of PCIe
-        only if a kernel without an int16 front end asks for it)"""
+        """device pointer of the clips as the plan's float type (int16 batches: converted once, on the device, when a kernel
+        without an int16 front end asks for it)"""
         if not self.int16:
             return self.buf.ptr
         if self._f is None:
-            raw = np.empty((self.n_clips, self.n_samples), np.int16)
-            self.buf.download(raw)
-            _capi.stream_sync()
-            self._f = _capi.DeviceBuffer(max(raw.size * 4, 8))
-            self._f.upload(raw.astype(np.float32))
-            _capi.stream_sync()
+            n = self.n_clips * self.n_samples
+            self._f = _capi.DeviceBuffer(max(n * 4, 8))
+            _capi.check(_capi.lib().sg_convert_i16(C.c_void_p(self.buf.ptr), C.c_void_p(self._f.ptr), n, None))   # on the device
         return self._f.ptr
 
     def stft(self, fs=1.0, window=("tukey", .25), nperseg=None, hop=None, detrend="constant", scaling="density",
@@ -361,7 +358,7 @@ class DeviceClips:
         n_frames, n_bins = plan.n_frames(self.n_samples), plan.n_bins
         isz = np.dtype(self.cdt).itemsize
         out = _capi.DeviceBuffer(max(self.n_clips * n_frames * n_bins * isz, 8))
-        i16 = self.int16 and plan.kernel != "bluestein"
+        i16 = self.int16 and plan.kernel in ("r8x3", "stockham")      # kernels with int16 loads of their own; the others read the float copy
         plan.stft(self.buf.ptr if i16 else self._float_ptr(), self.n_samples, self.n_samples, self.n_clips, out.ptr,
                   n_frames * n_bins, int16=i16)
         return DeviceSpectrogram(out, self.code, self.n_clips, n_frames, n_bins, _capi.freqs(nfft, fs),

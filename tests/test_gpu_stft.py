@@ -103,6 +103,38 @@ def test_r8x3_variants(sp, hop, detrend, mode):
     assert_spec_close(s, so, time_axis=-1)
 
 
+@pytest.mark.parametrize("nperseg,hop", [(256, 64), (512, 128), (512, 127), (1024, 256), (2048, 128), (4096, 1024), (2048, 333), (1000, 250)])
+def test_int16_pcm_batches_every_family(sp, nperseg, hop):
+    """int16 PCM (16-bit WAV): the result must equal the float call on the same values BIT FOR BIT in every kernel family -- r8x3
+    and the LDS kernel load int16 themselves, rsmall / rbig batches convert once into a stream-ordered workspace
+    (sg_stft_i16 -> sg_convert_i16 + the float kernel), small calls and odd hops stay on the LDS kernel -- and match the oracle."""
+    from spectro import engine
+    rng = np.random.default_rng(nperseg + hop)
+    for n_clips, n in ((1, nperseg + hop * 20 + 3), (5, 70001)):          # a GUI-sized call and a batch above the conversion threshold
+        xi = (rng.standard_normal((n_clips, n)) * 5000).astype(np.int16)
+        kw = dict(fs=44100.0, nperseg=nperseg, window="hann", noverlap=nperseg - hop)
+        f, t, s_i = sp.spectrogram(xi, **kw)
+        _, _, s_f = sp.spectrogram(xi.astype(np.float32), **kw)
+        assert s_i.dtype == np.float32
+        same_kernel = nperseg == 1024 or (n_clips * n >= (1 << 18) and hop % 2 == 0)
+        if same_kernel:
+            np.testing.assert_array_equal(s_i, s_f)
+        else:                                                             # small call / odd hop: int16 runs the LDS kernel
+            assert_spec_close(s_i, s_f, time_axis=-1)
+        _, _, so = orc.spectrogram(xi, **kw)
+        assert_spec_close(s_i, so, time_axis=-1)
+    dc = engine.DeviceClips(xi)                                           # int16 clips resident: the float copy is made on the device
+    try:
+        dev = dc.stft(fs=44100.0, window="hann", nperseg=nperseg, hop=hop)
+        if hop % 2 == 0 or nperseg in (1024, 1000):                       # the float copy runs the float call's kernel
+            np.testing.assert_array_equal(dev.to_host(), s_f)
+        else:
+            assert_spec_close(dev.to_host(), s_f, time_axis=-1)
+        dev.free()
+    finally:
+        dc.free()
+
+
 @pytest.mark.parametrize("nperseg,hop", [(1024, 64), (1024, 32), (1024, 16), (2048, 64), (2048, 128), (2048, 256), (2048, 32),
                                          (4096, 64), (4096, 128), (4096, 256), (4096, 16)])
 def test_sliding_window_walks(sp, nperseg, hop):
