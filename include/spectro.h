@@ -104,7 +104,7 @@ int sg_stream_sync(void* stream); /* blocks the caller */
  *            computed in `dtype` precision like scipy does
  * Supported on the device: every nfft from 2 to 2^20 in SG_F32 and SG_F64 -- register kernels for f32 nfft 256..4096, an LDS
  * Stockham kernel for the other powers of two up to 16384 (f32) / 8192 (f64), chirp-z (Bluestein) for everything else, in
- * LDS while the convolution buffer fits and in a stream-ordered HBM workspace above that (e.g. f64 nperseg 4097..8191,
+ * LDS while the convolution buffer fits and in the stream's HBM workspace (see sg_workspace_release) above that (e.g. f64 nperseg 4097..8191,
  * which the reference GUI's spin box reaches).
  */
 int sg_plan_create(sg_plan** plan, int nperseg, int nfft, int hop, const double* window,
@@ -139,8 +139,11 @@ int sg_stft(const sg_plan* plan, const void* x_dev, int64_t n_samples, int64_t c
  * Samples are used as-is (no 1/32768 scaling), i.e. like numpy's int16 -> float cast. */
 int sg_stft_i16(const sg_plan* plan, const int16_t* x_dev, int64_t n_samples, int64_t clip_stride,
                 int n_clips, float* out_dev, int64_t out_clip_stride, void* stream);
+/* Frees the per-stream workspaces the library keeps for int16 batches (float copy) and oversize chirp-z plans (they grow on
+ * demand and are otherwise held until the library is unloaded).  Waits for the devices concerned. */
+int sg_workspace_release(void);
 /* dst[i] = (float)src[i], i < n: int16 PCM to the f32 the plans compute in (exact).  sg_stft_i16 does this itself where a
- * kernel has no int16 loads of its own (batches on nperseg 256 / 512 / 2048 / 4096: a stream-ordered workspace, then the
+ * kernel has no int16 loads of its own (batches on nperseg 256 / 512 / 2048 / 4096: the stream's workspace, then the
  * float kernel); exported for callers that keep a converted copy across many calls (spectro.engine.DeviceClips). */
 int sg_convert_i16(const int16_t* src_dev, float* dst_dev, int64_t n, void* stream);
 /*

@@ -334,6 +334,52 @@ void* reduction_scratch(hipStream_t s) {
     return p;
 }
 
+// Larger per-(device, stream) workspace that grows on demand: the float copy of an int16 batch (sg_stft_i16 on rsmall / rbig plans),
+// the chirp-z convolution buffers beyond LDS size.  Work on one stream is ordered, so successive calls share it; growing frees
+// the old block (hipFree waits for the device).  hipMallocAsync / hipFreeAsync around each call looked like the natural tool and
+// is NOT used: on this ROCm build blocks from the stream-ordered pool came back with stretches of another allocation's data
+// in ~8 % of int16 batch calls (tools/repro_i16.py; plain hipMalloc: none in 150).  Held until sg_workspace_release().
+namespace {
+struct Workspace { void* ptr = nullptr; size_t bytes = 0; };
+std::mutex g_ws_mu;
+std::map<std::pair<int, hipStream_t>, Workspace> g_ws;
+}  // namespace
+
+void* stream_workspace(hipStream_t s, size_t bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(g_ws_mu);
+    Workspace& w = g_ws[{dev, s}];
+    if (w.bytes < bytes) {
+        if (w.ptr) { (void)hipStreamSynchronize(s); (void)hipFree(w.ptr); w.ptr = nullptr; w.bytes = 0; }
+        const size_t want = bytes + bytes / 4;
+        if (hipMalloc(&w.ptr, want) != hipSuccess) {
+            (void)hipGetLastError();
+            if (hipMalloc(&w.ptr, bytes) != hipSuccess) { (void)hipGetLastError(); w.ptr = nullptr; return nullptr; }
+            w.bytes = bytes;
+        } else {
+            w.bytes = want;
+        }
+    }
+    return w.ptr;
+}
+
+extern "C" int sg_workspace_release(void) {
+    std::lock_guard<std::mutex> lock(g_ws_mu);
+    for (auto& kv : g_ws) {
+        if (kv.second.ptr) {
+            int cur = 0;
+            (void)hipGetDevice(&cur);
+            (void)hipSetDevice(kv.first.first);
+            (void)hipDeviceSynchronize();
+            (void)hipFree(kv.second.ptr);
+            (void)hipSetDevice(cur);
+        }
+    }
+    g_ws.clear();
+    return SG_OK;
+}
+
 namespace {
 
 // how to walk band [k_lo, k_hi] of an (n_frames x n_bins) spectrum; `flat` = the band is every bin, so the data

@@ -126,13 +126,13 @@ static int convert_i16(const int16_t* src, float* dst, int64_t n, hipStream_t s)
 
 static int run_stft(const sg_plan* plan, StftArgs& a);
 
-// rsmall / rbig batches of int16 PCM: convert once into a stream-ordered float workspace (same clip stride, so the register
+// rsmall / rbig batches of int16 PCM: convert once into the stream's float workspace (same clip stride, so the register
 // kernel's alignment rules are unchanged) and run the float kernel -- ~10x the LDS kernel's rate.  Small calls (a GUI sweep)
-// keep the LDS kernel's own int16 loads: the workspace allocation would cost more than it saves.
+// keep the LDS kernel's own int16 loads.
 static int run_converted(const sg_plan* plan, StftArgs& a) {
     const int64_t span = static_cast<int64_t>(a.n_clips - 1) * a.clip_stride + a.n_samples;
-    void* work = nullptr;
-    SG_HIP(hipMallocAsync(&work, static_cast<size_t>(span) * sizeof(float), a.stream));
+    void* const work = stream_workspace(a.stream, static_cast<size_t>(span) * sizeof(float));
+    if (!work) { set_error("sg_stft_i16: no memory for the %lld-sample float workspace", static_cast<long long>(span)); return SG_ERR_HIP; }
     int rc = convert_i16(static_cast<const int16_t*>(a.x), static_cast<float*>(work), span, a.stream);
     if (rc == SG_OK) {
         StftArgs f = a;
@@ -140,7 +140,6 @@ static int run_converted(const sg_plan* plan, StftArgs& a) {
         f.in_i16 = 0;
         rc = run_stft(plan, f);
     }
-    (void)hipFreeAsync(work, a.stream);
     return rc;
 }
 

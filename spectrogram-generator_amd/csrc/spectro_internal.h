@@ -64,6 +64,7 @@ bool r8x3_f64_can_run(const sg_plan& p, const StftArgs& a);
 int r8x3_grid_waves(const sg_plan& p, int64_t total_frames, bool mel = false);   // waves (= min/max partials of the dB variant) of a launch
 // epilogue.hip: per-(device, stream) scratch of 256 KiB for reduction partials; fold of n (min, max) float pairs into mm[2]
 void* reduction_scratch(hipStream_t s);
+void* stream_workspace(hipStream_t s, size_t bytes);   // grows on demand, per (device, stream); nullptr when out of memory
 int fold_minmax_f32(const float* parts, int n_parts, float* mm_dev, hipStream_t s);
 int launch_rsmall(const sg_plan& p, const StftArgs& a);
 bool rsmall_can_run(const sg_plan& p, const StftArgs& a);

@@ -12,7 +12,7 @@
 // The L-point buffer lives in LDS while it fits (f32: nfft <= 8192, f64: nfft <= 4096); larger transforms -- f64 signals
 // with a non-power-of-two nperseg above 4096, which the GUI's 32..8192 spin box and scipy's nperseg := len(x) clamp both
 // reach, and every power of two beyond the Stockham kernel -- run the same butterflies on a per-workgroup slice of a
-// stream-ordered HBM workspace (hipMallocAsync / hipFreeAsync around the launch, so a plan stays re-entrant per stream);
+// per-stream HBM workspace (stream_workspace(): grows on demand, shared by the calls of a stream, so a plan stays re-entrant per stream);
 // that slice is L2-resident (<= 1 MiB per workgroup at the largest GUI size) and the path is a correctness net for
 // GUI-sized calls, not a throughput kernel.
 #include "spectro_internal.h"
@@ -197,18 +197,16 @@ int launch_t(const sg_plan& p, const StftArgs& a) {
         if (n_wg > cap) n_wg = cap;
         hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(n_wg)), dim3(kThreads), lds, a.stream, prm);
     } else {
-        // oversized: one L-point buffer per workgroup in a stream-ordered HBM workspace
+        // oversized: one L-point buffer per workgroup in the stream's HBM workspace
         const int64_t cap = static_cast<int64_t>(p.n_cu);
         if (n_wg > cap) n_wg = cap;
         const size_t bytes = static_cast<size_t>(n_wg) * p.bs_len * 2 * sizeof(T);
-        void* work = nullptr;
-        SG_HIP(hipMallocAsync(&work, bytes, a.stream));
+        void* const work = stream_workspace(a.stream, bytes);
+        if (!work) { set_error("stft_bluestein: no memory for the %zu-byte convolution workspace", bytes); return SG_ERR_HIP; }
         prm.work = static_cast<Cx<T>*>(work);
         hipLaunchKernelGGL((stft_bluestein_kernel<T, true>), dim3(static_cast<unsigned>(n_wg)), dim3(kThreads), red_bytes, a.stream, prm);
         const hipError_t le = hipGetLastError();
-        const hipError_t fe = hipFreeAsync(work, a.stream);
         if (le != hipSuccess) return hip_fail(le, "stft_bluestein (HBM workspace) launch");
-        if (fe != hipSuccess) return hip_fail(fe, "hipFreeAsync");
         return SG_OK;
     }
     hipError_t e = hipGetLastError();

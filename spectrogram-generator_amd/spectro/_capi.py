@@ -43,6 +43,7 @@ SIGNATURES = {
     "sg_memcpy2d": (_i, [_vp, _sz, _vp, _sz, _sz, _sz, _i, _vp]),
     "sg_memset": (_i, [_vp, _i, _sz, _vp]),
     "sg_convert_i16": (_i, [_vp, _vp, _i64, _vp]),
+    "sg_workspace_release": (_i, []),
     "sg_stream_create": (_i, [_pvp]),
     "sg_stream_destroy": (_i, [_vp]),
     "sg_stream_sync": (_i, [_vp]),

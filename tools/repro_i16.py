@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""int16 batches on rsmall / rbig plans against the float call on the same values (must be bit-identical): the reproducer that showed
+hipMallocAsync blocks carrying another allocation's data on this ROCm build; prints the failing cases and their count.
+python tools/repro_i16.py"""
+import sys, numpy as np
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "spectrogram-generator_amd"))
+import spectro
+from oracle import stft_oracle as orc
+rng = np.random.default_rng(5)
+fails = 0
+for it in range(150):
+    n_clips, N = int(rng.choice([33, 70, 16])), int(rng.integers(4000, 30000))
+    nper = int(rng.choice([256, 512, 2048, 4096])); hop = int(rng.choice([64, 128, 256, nper - nper // 8]))
+    N = max(N, nper + hop)
+    kw = dict(fs=500.0, nperseg=nper, noverlap=nper - hop, window="hann", detrend=False)
+    x = ((rng.standard_normal((n_clips, N)) * 1.3 + 0.6) * 3000).astype(np.int16)
+    f, t, s = spectro.spectrogram(x, **kw)
+    _, _, sf = spectro.spectrogram(x.astype(np.float32), **kw)
+    if not np.array_equal(s, sf) and n_clips * N >= (1 << 18) and hop % 2 == 0:
+        fails += 1
+        bad = np.argwhere(s != sf)
+        print("FAIL", it, n_clips, N, nper, hop, "bad clips", sorted(set(bad[:, 0].tolist()))[:10], "of", n_clips)
+print("fails", fails)
