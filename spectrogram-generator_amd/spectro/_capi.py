@@ -172,7 +172,7 @@ def _bucket(nbytes: int) -> int:
 
 
 def device_pool_clear():
-    """hipFree every pooled block (memory-tight callers, device switches, tests)."""
+    """hipFree every pooled block and the library's per-stream workspaces (memory-tight callers, device switches, tests)."""
     global _pool_bytes
     with _pool_lock:
         for ptrs in _pool_free.values():
@@ -180,6 +180,7 @@ def device_pool_clear():
                 lib().sg_free(C.c_void_p(p))
         _pool_free.clear()
         _pool_bytes = 0
+    lib().sg_workspace_release()
 
 
 class DeviceBuffer:
