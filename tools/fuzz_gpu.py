@@ -105,4 +105,54 @@ for it in range(pcases):
         pbad += 1
         print("PRODUCT FAIL", it, dict(n_clips=n_clips, N=N, hop=hop, fs=fs, detrend=detrend, band=(fmin, fmax)))
 print(f"{pcases - pbad}/{pcases} fused-product cases agree with the oracle")
-sys.exit(1 if (bad or pbad) else 0)
+
+# ---- batch APIs: pipelined ingest, resident clips, hop-shared sweep -- against the plain call on the same values ----
+from spectro.pipeline import stft_pipelined
+from spectro.sweep import hop_families
+bbad, bcases = 0, max(cases // 10, 20)
+for it in range(bcases):
+    nper = int(rng.choice([256, 512, 1024, 2048, 4096, 1000]))
+    hops = sorted({int(h) for h in rng.choice([16, 32, 64, 128, 256, 96, nper - nper // 8, int(rng.integers(1, nper + 1))], 3)})
+    n_clips = int(rng.choice([1, 3, 8, 21, 40]))
+    N = nper + int(rng.integers(0, 60)) * max(hops) + int(rng.integers(0, 200))
+    dt = rng.choice(["f32", "f64", "i16"])
+    x = rng.standard_normal((n_clips, N)) * rng.uniform(0.05, 2.0) + rng.uniform(-0.3, 0.3)
+    x = (x * 4000).astype(np.int16) if dt == "i16" else x.astype(np.float32 if dt == "f32" else np.float64)
+    fs = float(rng.choice([500.0, 48000.0]))
+    ok = True
+    try:
+        dc = engine.DeviceClips(x)
+        for hop in hops:
+            kw = dict(fs=fs, nperseg=nper, window="hann", noverlap=nper - hop)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                f, t, s = spectro.spectrogram(x, **kw)
+                fo, to, so = orc.spectrogram(x, **kw)
+            tol = 2e-4 if s.dtype == np.float32 else 1e-9
+            ref = np.abs(so).max(axis=-2, keepdims=True)
+            ok &= np.array_equal(t, to) and bool(np.all(np.abs(s - so) <= tol * ref + 1e-30))
+            fp, tp, sp_ = stft_pipelined(x, chunk_bytes=int(rng.choice([1, 1 << 16, 1 << 20, 1 << 26])), **kw)
+            ok &= np.array_equal(tp, to) and bool(np.all(np.abs(sp_ - so) <= tol * ref + 1e-30))
+            dev = dc.stft(fs=fs, window="hann", nperseg=nper, hop=hop)
+            sd = dev.to_host()
+            dev.free()
+            ok &= sd.shape == so.shape and bool(np.all(np.abs(sd - so) <= tol * ref + 1e-30))
+        for g, fam in hop_families(hops):                      # coarser hops are row subsets of the family's transform
+            if len(fam) > 1:
+                dev = dc.stft(fs=fs, window="hann", nperseg=nper, hop=g)
+                base = dev.to_host()
+                dev.free()
+                for h in fam:
+                    dev = dc.stft(fs=fs, window="hann", nperseg=nper, hop=h)
+                    own = dev.to_host()
+                    dev.free()
+                    ok &= bool(np.array_equal(base[..., ::h // g][..., :own.shape[-1]], own))
+        dc.free()
+    except Exception as e:          # noqa: BLE001
+        ok = False
+        print("EXC", repr(e))
+    if not ok:
+        bbad += 1
+        print("BATCH FAIL", it, dict(n_clips=n_clips, N=N, dt=str(dt), nperseg=nper, hops=hops, fs=fs))
+print(f"{bcases - bbad}/{bcases} batch-API cases agree with the oracle")
+sys.exit(1 if (bad or pbad or bbad) else 0)
