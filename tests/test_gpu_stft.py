@@ -135,6 +135,26 @@ def test_int16_pcm_batches_every_family(sp, nperseg, hop):
         dc.free()
 
 
+def test_int16_batches_many_calls_in_a_row(sp):
+    """Back-to-back int16 batches of changing size on the plans that convert into the stream's workspace: each must equal the
+    float call bit for bit.  (The first version of that path took its workspace from hipMallocAsync and returned foreign data in
+    ~8 % of such calls on this ROCm build -- tools/repro_i16.py; only a many-call loop shows it.)"""
+    rng = np.random.default_rng(5)
+    for it in range(80):
+        n_clips, n = int(rng.choice([33, 70, 16])), int(rng.integers(4000, 30000))
+        nper = int(rng.choice([256, 512, 2048, 4096]))
+        hop = int(rng.choice([64, 128, 256, nper - nper // 8]))
+        n = max(n, nper + hop)
+        kw = dict(fs=500.0, nperseg=nper, noverlap=nper - hop, window="hann", detrend=False)
+        x = ((rng.standard_normal((n_clips, n)) * 1.3 + 0.6) * 3000).astype(np.int16)
+        _, _, s = sp.spectrogram(x, **kw)
+        _, _, sf = sp.spectrogram(x.astype(np.float32), **kw)
+        if n_clips * n >= (1 << 18):
+            np.testing.assert_array_equal(s, sf, err_msg=f"call {it}: {n_clips} x {n}, nperseg {nper}, hop {hop}")
+        else:
+            assert_spec_close(s, sf, time_axis=-1)
+
+
 @pytest.mark.parametrize("nperseg,hop", [(1024, 64), (1024, 32), (1024, 16), (2048, 64), (2048, 128), (2048, 256), (2048, 32),
                                          (4096, 64), (4096, 128), (4096, 256), (4096, 16)])
 def test_sliding_window_walks(sp, nperseg, hop):
