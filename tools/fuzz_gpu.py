@@ -155,4 +155,52 @@ for it in range(bcases):
         bbad += 1
         print("BATCH FAIL", it, dict(n_clips=n_clips, N=N, dt=str(dt), nperseg=nper, hops=hops, fs=fs))
 print(f"{bcases - bbad}/{bcases} batch-API cases agree with the oracle")
-sys.exit(1 if (bad or pbad or bbad) else 0)
+
+# ---- what PlotEngine does with one GUI-sized signal (A8-A13): mask, store, display image, HMM features, band powers ----
+gbad, gcases = 0, max(cases // 5, 40)
+for it in range(gcases):
+    nper = int(rng.integers(1, 257)) * 32                      # the GUI's spin box: 32 ... 8192 in steps of 32
+    N = int(rng.integers(200, 60000))
+    fs = float(rng.choice([500.0, 2000.0, 10000.0, 20000.0]))
+    f64 = rng.random() < 0.7                                   # the reference's recordings are float64
+    x = rng.standard_normal(N) * rng.uniform(0.01, 50.0) + rng.uniform(-5, 5)
+    x = x if f64 else x.astype(np.float32)
+    fmin, fmax = sorted(rng.uniform(0, fs / 2 * 1.1, 2))
+    if rng.random() < 0.3:
+        fmin = 0.0
+    log_scale = bool(rng.random() < 0.6)
+    ok = True
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            fo, to, so = orc.spectrogram(x, fs=fs, nperseg=nper)
+            dev = engine.stft(x, fs=fs, nperseg=nper)
+        gm = None if rng.random() < 0.5 else float(so.max() * rng.uniform(0.5, 3.0)) if so.size else None
+        lf, lt, lsxx, img = orc.plot_image(fo, to, so, fmin, fmax, log_scale, gm)
+        k_lo, k_hi = engine.bin_range(dev.f, fmin, fmax)
+        ok &= np.array_equal(dev.f, fo) and np.array_equal(dev.t, to) and (k_hi - k_lo + 1) == lf.size
+        if lf.size and so.shape[-1]:
+            tol = 1e-9 if f64 else 2e-4
+            sl = dev.band_slice(k_lo, k_hi)
+            ok &= sl.shape == lsxx.shape and bool(np.all(np.abs(sl - lsxx) <= tol * np.abs(so).max() + 1e-300))
+            if f64 or not log_scale:                           # the f32 log image is ill-conditioned at its darkest bin (tests/test_gpu_db.py)
+                got = dev.image(k_lo, k_hi, log_scale, gm)
+                ok &= got.shape == img.shape and bool(np.abs(got - img).max() <= (1e-6 if f64 else 2e-4))
+            feats = dev.features(k_lo, k_hi)
+            lp = np.log10(lsxx.sum(axis=0) + 1e-20)
+            ok &= bool(np.allclose(np.asarray(feats)[..., 0].reshape(-1), lp, atol=1e-9 if f64 else 3e-5))
+            bands = [(0.0, 4.0), (4.0, 8.0), (8.0, 13.0), (13.0, 30.0), (30.0, 80.0), (80.0, 250.0)]
+            bp = orc.band_powers(lf, lsxx, {str(i): b for i, b in enumerate(bands)})
+            ranges = [(int(np.searchsorted(lf, lo, "left")) + k_lo, int(np.searchsorted(lf, hi, "left")) + k_lo) for lo, hi in bands]
+            tot = dev.band_totals([(k_lo, k_hi + 1)] + ranges)
+            if tot[0] >= 1e-18:
+                ok &= bool(np.allclose(tot[1:] / tot[0], [bp[str(i)] for i in range(len(bands))], rtol=1e-9 if f64 else 1e-4, atol=1e-12))
+        dev.free()
+    except Exception as e:          # noqa: BLE001
+        ok = False
+        print("EXC", repr(e))
+    if not ok:
+        gbad += 1
+        print("GUI FAIL", it, dict(N=N, nperseg=nper, fs=fs, f64=bool(f64), band=(fmin, fmax), log_scale=log_scale))
+print(f"{gcases - gbad}/{gcases} GUI-flow cases agree with the oracle")
+sys.exit(1 if (bad or pbad or bbad or gbad) else 0)
