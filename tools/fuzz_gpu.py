@@ -203,4 +203,37 @@ for it in range(gcases):
         gbad += 1
         print("GUI FAIL", it, dict(N=N, nperseg=nper, fs=fs, f64=bool(f64), band=(fmin, fmax), log_scale=log_scale))
 print(f"{gcases - gbad}/{gcases} GUI-flow cases agree with the oracle")
-sys.exit(1 if (bad or pbad or bbad or gbad) else 0)
+
+# ---- streaming (cfg5): ragged chunks in, frames out == the offline call on the whole recording ----
+from spectro.stream import StreamingSTFT
+sbad, scases = 0, max(cases // 20, 10)
+for it in range(scases):
+    nper = int(rng.choice([96, 256, 512, 1024, 2048, 4096, 1000]))
+    hop = int(rng.choice([nper // 4, nper // 2, nper, max(1, nper // 16)])) if rng.random() < 0.6 else int(rng.integers(1, nper + 1))
+    n_ch = int(rng.choice([1, 2, 8]))
+    total = nper * int(rng.integers(2, 9)) + int(rng.integers(0, 999))
+    max_chunk = int(rng.choice([64, 500, 4096, 10000]))
+    fs = float(rng.choice([8000.0, 96000.0]))
+    x = (rng.standard_normal((n_ch, total)) * 0.3 + 0.05).astype(np.float32)
+    ok = True
+    try:
+        st = StreamingSTFT(n_ch, fs, nper, hop, window="hann", max_chunk=max_chunk)
+        pos, ts, outs = 0, [], []
+        while pos < total:
+            n = min(int(rng.integers(0, max_chunk + 1)), total - pos)
+            t, sx = st.feed(x[:, pos:pos + n])
+            ts.append(t); outs.append(sx)
+            pos += n
+        st.close()
+        t_all, s_all = np.concatenate(ts), np.concatenate(outs, axis=-1)
+        fo, to, so = orc.spectrogram(x, fs=fs, nperseg=nper, window="hann", noverlap=nper - hop)
+        ref = np.abs(so).max(axis=-2, keepdims=True)
+        ok = s_all.shape == so.shape and np.array_equal(t_all, to) and bool(np.all(np.abs(s_all - so) <= 2e-4 * ref + 1e-30))
+    except Exception as e:          # noqa: BLE001
+        ok = False
+        print("EXC", repr(e))
+    if not ok:
+        sbad += 1
+        print("STREAM FAIL", it, dict(n_ch=n_ch, total=total, nperseg=nper, hop=hop, max_chunk=max_chunk, fs=fs))
+print(f"{scases - sbad}/{scases} streaming cases agree with the oracle")
+sys.exit(1 if (bad or pbad or bbad or gbad or sbad) else 0)
