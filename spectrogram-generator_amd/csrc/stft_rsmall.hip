@@ -8,6 +8,10 @@
 //   pass 2/3: the radix-8 passes of the 1024 kernel with the register index v = g*R + r
 //   after pass 3 lane l = lu + L*g (L = 8R lanes per frame) holds Z_g[lu + L*t], t = 0..7.
 // Index maps and LDS bank behaviour are replayed in tools/sim_rsmall.py.
+// (A register sliding window as in stft_r8x3.hip / stft_rbig.hip -- a group's G frames span R + G - 1 blocks of 128 samples, the
+//  next group G blocks further, G loads per group instead of 8 -- was built and measured in round 2 at hops 128 / 64: 0.121 /
+//  0.065 ms against 0.120 / 0.066 ms (nfft 256) and 0.230 / 0.118 against 0.217 / 0.118 ms (nfft 512) per 64-clip batch.  These
+//  kernels run below the power cap at 2.4 GHz: the re-read samples are not what limits them.  Not kept.)
 // Algorithmic HBM bytes per frame: hop*4 + (64R+1)*4.
 #include "spectro_internal.h"
 #include "fft_wave.h"

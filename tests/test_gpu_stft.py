@@ -156,10 +156,11 @@ def test_int16_batches_many_calls_in_a_row(sp):
 
 
 @pytest.mark.parametrize("nperseg,hop", [(1024, 64), (1024, 32), (1024, 16), (2048, 64), (2048, 128), (2048, 256), (2048, 32),
-                                         (4096, 64), (4096, 128), (4096, 256), (4096, 16)])
+                                         (4096, 64), (4096, 128), (4096, 256), (4096, 16),
+                                         (256, 128), (256, 64), (256, 16), (512, 128), (512, 64), (512, 32)])
 def test_sliding_window_walks(sp, nperseg, hop):
-    """Register sliding windows: hops 128 / 256 directly, hops 64 / 32 / 16 as 2 / 4 / 8 interleaved hop-128 sequences (r8x3 and
-    rbig): every frame count from one frame up, several clips, spectrum + fused band power against the oracle / the written
+    """Register sliding windows: hops 128 / 256 directly, hops 64 / 32 / 16 as 2 / 4 / 8 interleaved hop-128 sequences (r8x3, rbig
+    and rsmall): every frame count from one frame up, several clips, spectrum + fused band power against the oracle / the written
     spectrum; at 1024 also the fused dB image."""
     from spectro import _capi, engine
     from spectro.signal import plan_for
@@ -178,11 +179,12 @@ def test_sliding_window_walks(sp, nperseg, hop):
         d_in, d_bp = _capi.DeviceBuffer(x.nbytes), _capi.DeviceBuffer(3 * n_frames * 4)
         d_in.upload(x)
         _capi.check(_capi.lib().sg_memset(C.c_void_p(d_bp.ptr), 0xFF, 3 * n_frames * 4, None))
-        plan.band_power(d_in.ptr, n, n, 3, 5, 300, d_bp.ptr, n_frames)
+        k_hi = min(300, nperseg // 2)
+        plan.band_power(d_in.ptr, n, n, 3, 5, k_hi, d_bp.ptr, n_frames)
         bp = np.empty((3, n_frames), np.float32)
         d_bp.download(bp)
         _capi.stream_sync()
-        ref = s[:, 5:301, :].astype(np.float64).sum(axis=1)
+        ref = s[:, 5:k_hi + 1, :].astype(np.float64).sum(axis=1)
         assert np.all(np.abs(bp - ref) <= 2e-6 * s.astype(np.float64).sum(axis=1) + 1e-30)
         d_in.free(); d_bp.free()
     if nperseg != 1024:

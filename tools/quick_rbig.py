@@ -12,7 +12,7 @@ x = (np.random.default_rng(1).standard_normal((n_clips, N)) * 0.1).astype(np.flo
 ins = [_capi.DeviceBuffer(x.nbytes) for _ in range(4)]
 for b in ins: b.upload(x)
 secs = float(os.environ.get("QB_SECS", "0.6"))
-for n in (2048, 4096):
+for n in [int(v) for v in os.environ.get("QR_SIZES", "2048,4096").split(",")]:
     for hop in (64, 128, 256):
         plan = _capi.Plan(n, n, hop, get_window("hann", n), 1, 48000.0, 0, 0, _capi.F32)
         nf = plan.n_frames(N)
