@@ -23,8 +23,10 @@
  *   - spectra are FRAME-MAJOR on the device: out[clip][frame][bin]; the Python
  *     shim returns the transposed view [bin][frame] exactly like
  *     scipy/signal/_spectral_py.py:2153 (moveaxis of a frame-major result).
- *   - re-entrant per (plan, stream); no global mutable state besides the
- *     thread-local error string.
+ *   - re-entrant per (plan, stream).  Besides the thread-local error string the library keeps per-(device, stream) scratch (a small
+ *     reduction buffer, a workspace that grows on demand: sg_workspace_release) that the calls of a stream share in stream order;
+ *     entry points that hand data from one launch to the next through it (min/max and band totals: partials -> fold; sg_stft_db;
+ *     int16 batches: convert -> transform) submit their launches under one internal lock, so host threads may share a stream.
  */
 #ifndef SPECTRO_H
 #define SPECTRO_H

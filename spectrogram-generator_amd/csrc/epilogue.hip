@@ -345,6 +345,11 @@ std::mutex g_ws_mu;
 std::map<std::pair<int, hipStream_t>, Workspace> g_ws;
 }  // namespace
 
+std::recursive_mutex& launch_sequence_mutex() {
+    static std::recursive_mutex mu;
+    return mu;
+}
+
 void* stream_workspace(hipStream_t s, size_t bytes) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
@@ -397,6 +402,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 template <typename T>
 int minmax_t(const void* spec, int64_t n_frames, int n_bins, int k_lo, int k_hi, void* mm, hipStream_t s) {
+    std::lock_guard<std::recursive_mutex> seq(launch_sequence_mutex());
     T* const parts = static_cast<T*>(reduction_scratch(s));
     if (!parts) { set_error("minmax: no scratch memory"); return SG_ERR_HIP; }
     bool flat;
@@ -599,6 +605,7 @@ int sg_band_totals(const void* spec_dev, int dtype, int64_t n_frames, int n_bins
     }
     auto s = static_cast<hipStream_t>(stream);
     if (n_frames == 0) { SG_HIP(hipMemsetAsync(sums_dev, 0, sizeof(double) * n_bands, s)); return SG_OK; }
+    std::lock_guard<std::recursive_mutex> seq(launch_sequence_mutex());
     double* const parts = static_cast<double*>(reduction_scratch(s));
     if (!parts) { set_error("band_totals: no scratch memory"); return SG_ERR_HIP; }
     const unsigned g = grid_for((n_frames + kRowsPerStep - 1) / kRowsPerStep * 64, kMaxParts);

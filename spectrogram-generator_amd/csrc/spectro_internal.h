@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <string>
+#include <mutex>
 #include <vector>
 #include "spectro.h"
 #include "host_shim.h"
@@ -64,6 +65,10 @@ bool r8x3_f64_can_run(const sg_plan& p, const StftArgs& a);
 int r8x3_grid_waves(const sg_plan& p, int64_t total_frames, bool mel = false);   // waves (= min/max partials of the dB variant) of a launch
 // epilogue.hip: per-(device, stream) scratch of 256 KiB for reduction partials; fold of n (min, max) float pairs into mm[2]
 void* reduction_scratch(hipStream_t s);
+// Sequences of launches that hand data to each other through reduction_scratch / stream_workspace (partials -> fold, convert ->
+// transform) hold this lock while they are being SUBMITTED, so that two host threads using the same stream cannot interleave their
+// launches (the stream then runs each sequence back to back).  Recursive: a sequence may contain another.
+std::recursive_mutex& launch_sequence_mutex();
 void* stream_workspace(hipStream_t s, size_t bytes);   // grows on demand, per (device, stream); nullptr when out of memory
 int fold_minmax_f32(const float* parts, int n_parts, float* mm_dev, hipStream_t s);
 int launch_rsmall(const sg_plan& p, const StftArgs& a);

@@ -567,6 +567,47 @@ def test_concurrent_callers_share_the_staging_and_the_pools(sp):
     assert not errors, errors
 
 
+def test_concurrent_batches_share_the_stream_scratch(sp):
+    """Host threads on the SAME (default) stream: int16 batches go through the stream's float workspace (convert, then transform)
+    and the display epilogue through the stream's reduction scratch (partials, then fold) -- each such sequence must reach the
+    stream back to back, whoever else is submitting (launch_sequence_mutex)."""
+    import threading
+    from spectro import engine
+    rng = np.random.default_rng(123)
+    jobs = []
+    for i in range(6):
+        nper = (256, 512, 2048, 4096, 512, 2048)[i]
+        x = ((rng.standard_normal((20 + i, 15000 + 1111 * i)) * 0.7 + 0.2) * 3000).astype(np.int16)
+        kw = dict(fs=8000.0, nperseg=nper, window="hann", noverlap=nper - nper // 4)
+        jobs.append((x, kw, sp.spectrogram(x.astype(np.float32), **kw)[2]))
+    xf = (rng.standard_normal((4, 60000)) * 0.3).astype(np.float32)
+    dev = engine.stft(xf, fs=8000.0, nperseg=512)
+    img_ref = dev.image(3, 200, True, None)
+    errors = []
+
+    def batch_worker(idx):
+        try:
+            x, kw, ref = jobs[idx]
+            for _ in range(12):
+                np.testing.assert_array_equal(sp.spectrogram(x, **kw)[2], ref)
+        except Exception as e:                      # noqa: BLE001 - reported below
+            errors.append((idx, repr(e)[:300]))
+
+    def image_worker():
+        try:
+            for _ in range(60):
+                np.testing.assert_array_equal(dev.image(3, 200, True, None), img_ref)
+        except Exception as e:                      # noqa: BLE001
+            errors.append(("image", repr(e)[:300]))
+    threads = [threading.Thread(target=batch_worker, args=(i,)) for i in range(6)] + [threading.Thread(target=image_worker) for _ in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    dev.free()
+    assert not errors, errors
+
+
 def test_axis_argument(sp):
     rng = np.random.default_rng(8)
     x = rng.standard_normal((700, 3)).astype(np.float32)
