@@ -30,6 +30,12 @@ namespace {
 constexpr int kS1 = 72, kS2 = 66, kSlab = 8 * kS1;       // 576 elements per plane
 constexpr int kWaves = 4;                                // per workgroup
 constexpr int kOcc = 2;                                  // waves per SIMD
+#ifndef SG_R8D_PRIO
+// wave priority rises along a group (pass 1 -> stores), as in stft_r8x3.hip -- for the kernels that carry several frames per
+// wave only: same-box A/B per 64-clip batch, nfft 512 hop 128: 192 us with, 200-203 us without; nfft 1024 hop 256: 195-196 us
+// with, 190-192 us without (so R = 8 runs without)
+#define SG_R8D_PRIO 1
+#endif
 
 struct cd { double x, y; };
 __device__ __forceinline__ cd cadd(cd a, cd b) { return {a.x + b.x, a.y + b.y}; }
@@ -122,6 +128,7 @@ template <int L> __device__ __forceinline__ double group_sum(double v) {     // 
 template <int R, bool DETREND, int MODE>
 __global__ __launch_bounds__(64 * kWaves, kOcc) void stft_reg_f64_kernel(const R8DParams p) {
     constexpr int G = 8 / R, M = 64 * R, L = 8 * R, NB = M + 1, RS = M + 8;
+    constexpr bool kPrio = SG_R8D_PRIO && R < 8;
     static_assert(G * RS <= kSlab, "split regions must fit the slab");
     __shared__ __attribute__((aligned(16))) double lds[kWaves * 2 * kSlab];
     const int lane = threadIdx.x & 63;
@@ -175,6 +182,7 @@ __global__ __launch_bounds__(64 * kWaves, kOcc) void stft_reg_f64_kernel(const R
 #pragma unroll
         for (int v = 0; v < 8; ++v) a[v] = nxt[v];
         load_group(more ? clip_n : clip, more ? gi_n : gi, nxt);
+        if (kPrio) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             if (DETREND) {                                               // A3 (scipy:2191, detrend 'constant')
@@ -199,6 +207,7 @@ __global__ __launch_bounds__(64 * kWaves, kOcc) void stft_reg_f64_kernel(const R
         for (int b = 0; b < 8; ++b) a[b] = sl.get(x1r + b * kS1);
         wave_lds_fence();
         // ---- pass 2 ----
+        if (kPrio) __builtin_amdgcn_s_setprio(1);
         radix8(a);
 #pragma unroll
         for (int s = 1; s < 8; ++s) a[s] = cmul(a[s], t2[s - 1]);
@@ -209,12 +218,14 @@ __global__ __launch_bounds__(64 * kWaves, kOcc) void stft_reg_f64_kernel(const R
         for (int j = 0; j < 8; ++j) a[j] = sl.get(x2r + j * kS2);
         wave_lds_fence();
         // ---- pass 3: lane lu of group g3 holds Z_g[lu + L t] ----
+        if (kPrio) __builtin_amdgcn_s_setprio(2);
         radix8(a);
 #pragma unroll
         for (int t = 4; t < 8; ++t) sl.put(x3w + L * t, a[t]);
         if (lu == 0) sl.put(g3 * RS + M, a[0]);                          // Z_g[M] := Z_g[0]
         wave_lds_fence();
         // ---- split pass + |X|^2 (A5 tail, A6) ----
+        if (kPrio) __builtin_amdgcn_s_setprio(3);
         const int f = gi * G + g3;
         const bool live = f < p.n_frames;
         double* const orow = p.out + static_cast<int64_t>(clip) * p.out_clip_stride +
