@@ -13,11 +13,17 @@ max-over-ranks time and -- after the timed region, reported separately as ``gath
 gather of a reduced product (per-frame band power) to rank 0, which is the one exchange the path
 has (``--gather-full`` also times the full spectra).  Rank 0 prints ONE JSON line.
 
-What bounds the kernel is part of the line: ``roofline`` is the HBM roof (the graded fraction),
-``roofline.valu`` the VALU-issue roof, ``fp32_flops`` the arithmetic rate, and ``power`` the board power,
-power cap and shader clock read from the card's hwmon sensors during an untimed leg of back-to-back
-launches after the timed region -- the kernel runs AT the 1400 W cap (sclk ~1.9 of 2.4 GHz), so its time
-is energy / power rather than bytes / bandwidth or slots / issue rate.
+What bounds the kernel is part of the line: ``roofline`` is the HBM roof (the graded fraction, priced with the
+SAME clock as ``value``: the host clock around the barrier-bracketed region; the HIP-event time of the same region
+is reported beside it under its own name), ``roofline.valu`` the VALU-issue roof, ``fp32_flops`` the arithmetic
+rate, ``power`` the board power, power cap and shader clock read from the card's hwmon sensors during an untimed
+leg of back-to-back launches after the timed region, and ``limiter`` what an untimed A/B of the same launch on
+zero-filled inputs says (MI355X_MICROARCH.md, DVFS give-back item 1: zero data frees the clock; if the launch does
+not get faster with it, neither the power cap nor the issue rate is what bounds it).  DESIGN.md section 5.
+
+With ``--gpus N`` (N > 1) and no torch.distributed environment the script starts its own N ranks
+(``python -m torch.distributed.run --nproc-per-node N``) as a child process before touching the GPU and relays
+rank 0's line; under a launcher whose WORLD_SIZE differs from ``--gpus`` it exits non-zero.
 
 Defaults (500 timed steps after 100 warm-up steps, ~60 ms of GPU time) are long enough to get past the chip's
 power-management transient: the first ~12 launches run at 92 us, the next ~100 at up to 138 us, then the
@@ -77,6 +83,9 @@ def parse():
     ap.add_argument("--telemetry-s", type=float, default=1.5,
                     help="seconds of untimed back-to-back launches AFTER the timed region during which rank 0 reads board "
                          "power and shader clock from the card's hwmon nodes (0 disables)")
+    ap.add_argument("--no-limiter-leg", action="store_true", help="skip the untimed zero-filled-input A/B the `limiter` entry is derived from")
+    ap.add_argument("--master-port", type=int, default=0, help="--gpus N > 1 without a launcher: rendezvous port of the ranks this script starts (0: pick a free one)")
+    ap.add_argument("--dry-run-spawn", action="store_true", help="print the launcher command --gpus N would start, as JSON, and exit (no GPU needed)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the (untimed-region) gather measurement")
     ap.add_argument("--gather-full", action="store_true", help="N > 1: also time the gather of the full spectra to rank 0")
     return ap.parse_args()
@@ -149,17 +158,59 @@ class Telemetry:
                 "n_samples": len(rows)}
 
 
+def spawn_command(args, argv):
+    """The launcher command for --gpus N > 1 when this process is not already a rank: one rank per GPU on this node."""
+    port = args.master_port
+    if not port:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def spawn_ranks(args, argv):
+    """Start the ranks as a CHILD process (this parent has not touched the GPU: no torch import yet) and relay rank 0's line."""
+    import subprocess
+    cmd = spawn_command(args, argv)
+    if args.dry_run_spawn:
+        print(json.dumps({"spawn": cmd, "n_ranks": args.gpus}))
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        print(f"[bench] the {args.gpus}-rank child run failed (exit code {proc.returncode}, JSON line {'found' if line else 'missing'})", file=sys.stderr)
+        return proc.returncode or 1
+    if json.loads(line).get("n_gpus") != args.gpus:
+        print(f"[bench] the child run reports n_gpus={json.loads(line).get('n_gpus')}, wanted {args.gpus}", file=sys.stderr)
+        return 1
+    print(line, flush=True)
+    return 0
+
+
 def main():
     args = parse()
+    in_launcher = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if args.dry_run_spawn or (args.gpus > 1 and not in_launcher):
+        raise SystemExit(spawn_ranks(args, [a for a in sys.argv[1:] if a != "--dry-run-spawn"]))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to report a line "
+                         f"whose n_gpus is not the one asked for")
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
     # Rehearsal switch for a 1-GPU box: SPECTRO_BENCH_SAME_GPU=1 puts every rank on cuda:0 and uses gloo for the
@@ -263,6 +314,14 @@ def main():
         except Exception as e:                                    # sensors are a report, never a failure
             print(f"[bench] telemetry unavailable: {e}", file=sys.stderr)
 
+    # what bounds the launch: the same binary on zero-filled inputs, back to back with the random ones, each with its own clock reading
+    limiter = None
+    if rank == 0 and n_clips > 0 and not args.no_limiter_leg:
+        try:
+            limiter = time_limiter_leg(_capi, plan, xs, outs, n_clips, n_frames, dev, stream)
+        except Exception as e:
+            print(f"[bench] limiter leg failed: {e}", file=sys.stderr)
+
     # the reference's literal call (PlotEngine.py:113: Tukey(0.25), hop 896) on the same clips, f32 and -- what the reference's
     # loaders hand over -- f64: reported beside cpu_baseline.reference_mode, never part of `value`
     ref_mode = None
@@ -277,8 +336,11 @@ def main():
         gather = time_gather(args, plan, xs[0], outs[0], n_clips, n_frames, dev, same_gpu, world, rank, stream)
 
     if rank == 0:
+        # ONE clock for the graded figures: the host clock around the barrier + synchronize bracketed region (the contract's clock)
+        # prices `value`, `ms_per_step` and `roofline.achieved / frac`; the HIP-event time of the same region is named as such.
         value = total_frames_per_step * args.steps / elapsed_max
-        launch_s = dev_ms_max / 1e3 / args.steps
+        launch_s = elapsed_max / args.steps
+        launch_s_events = dev_ms_max / 1e3 / args.steps
         per_gpu_fps = frames_per_step / launch_s
         achieved = per_gpu_fps * BYTES_PER_FRAME / 1e9
         sclk = (power or {}).get("sclk_MHz") or SCLK_MAX_MHZ
@@ -305,12 +367,17 @@ def main():
                        "clips_per_gpu": n_clips, "frames_per_step_per_gpu": frames_per_step,
                        "sharding": "clips over ranks, no data-path collective", "kernel": plan.kernel,
                        "buffer_sets": N_BUFFER_SETS},
-            # priced against the HBM roof (achieved / peak / frac are bytes); the VALU issue roof sits at about the same
-            # fraction ("valu"), and what actually stops the kernel from running faster is the board power cap ("power" / "limiter")
+            # priced against the HBM roof (achieved / peak / frac are bytes); "valu" is the VALU issue roof, "limiter" what a
+            # zero-input A/B of the same launch says about the clock's part in it
             "roofline": {"bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": hbm_frac, "traffic": load_traffic(),
+                         "traffic_source": "profiles/traffic_latest.json: FETCH_SIZE x 2 + WRITE_SIZE per launch from a committed rocprofv3 "
+                                           "--pmc run of this kernel on this workload (tools/profile_round.sh); NOT measured in this run",
+                         "clock": "host clock around the barrier-bracketed timed region, the same one as `value` and `ms_per_step`",
                          "kernel": "stft1024_r8x3_kernel", "us_per_launch": launch_s * 1e6,
+                         "us_per_launch_hip_events": launch_s_events * 1e6,
+                         "frac_hip_events": frames_per_step / launch_s_events * BYTES_PER_FRAME / 1e9 / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_frame": BYTES_PER_FRAME,
                          "read_only_frac": per_gpu_fps * HOP * 4 / 1e9 / HBM_PEAK_GBS,
                          "practical_hbm_GBs_for_this_mix": 5500.0,      # profiles/r02_ubench_hbm_peaks.txt: 1 read : 2 write
@@ -325,11 +392,10 @@ def main():
         }
         if power:
             res["power"] = power
-            at_cap = bool(power.get("board_W") and power.get("cap_W") and power["board_W"] >= 0.97 * power["cap_W"])
-            res["limiter"] = ("board power cap: time = energy per launch / cap (DESIGN.md section 5)" if at_cap
-                              else "below the power cap")
             if power.get("board_W"):
                 res["power"]["uJ_per_frame"] = power["board_W"] * power["us_per_launch_during_sample"] / max(frames_per_step, 1)
+        if limiter:
+            res["limiter"] = limiter
         if ref_mode:
             res["reference_mode"] = ref_mode
         if gather:
@@ -342,6 +408,66 @@ def main():
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def time_limiter_leg(_capi, plan, xs, outs, n_clips, n_frames, dev, stream, secs=0.5):
+    """Untimed A/B after the headline region: the SAME launch on the random clips and on zero-filled copies of them, alternating, `secs`
+    of back-to-back launches each, with the card's shader clock and board power sampled during each leg.  Zero data draws less power, so
+    the clock rises to its maximum; a launch bounded by the power cap or by instruction issue speeds up with the clock, one bounded by
+    the memory system does not.  -> dict (per-leg figures + the reading derived from them)."""
+    import torch
+    zeros = [torch.zeros_like(x) for x in xs[:2]]
+    legs = {"random": xs, "zeros": zeros}
+    rows = {k: [] for k in legs}
+    for _ in range(2):
+        for name, ins in legs.items():
+            def step(i, ins=ins):
+                b = i % len(ins)
+                plan.stft(ins[b].data_ptr(), N_SAMPLES, N_SAMPLES, n_clips, outs[b].data_ptr(), n_frames * N_BINS, stream=stream)
+            tel = Telemetry(_capi.device_pci_bus_id()).start()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < secs * 0.6:            # settle
+                for _ in range(32):
+                    step(n)
+                    n += 1
+                torch.cuda.synchronize(dev)
+            ev0.record()
+            m, t1 = 0, time.perf_counter()
+            while time.perf_counter() - t1 < secs * 0.4:
+                for _ in range(32):
+                    step(m)
+                    m += 1
+            ev1.record()
+            torch.cuda.synchronize(dev)
+            pw = tel.stop(skip_s=secs * 0.3) or {}
+            rows[name].append({"us_per_launch": ev0.elapsed_time(ev1) * 1e3 / m, "sclk_MHz": pw.get("sclk_MHz"), "board_W": pw.get("board_W")})
+    del zeros
+
+    def med(name, key):
+        v = [r[key] for r in rows[name] if r.get(key) is not None]
+        return statistics.median(v) if v else None
+    out = {"method": "same launch on random and on zero-filled inputs, alternating, 2 x %.1f s each, HIP events; hwmon medians per leg" % secs,
+           "random": {k: med("random", k) for k in ("us_per_launch", "sclk_MHz", "board_W")},
+           "zeros": {k: med("zeros", k) for k in ("us_per_launch", "sclk_MHz", "board_W")}}
+    ur, uz = out["random"]["us_per_launch"], out["zeros"]["us_per_launch"]
+    cr, cz = out["random"]["sclk_MHz"], out["zeros"]["sclk_MHz"]
+    out["time_ratio_zeros_over_random"] = uz / ur
+    if cr and cz:
+        out["clock_ratio_zeros_over_random"] = cz / cr
+        # share of the launch time that scales with the shader clock: t = t_fixed + t_clk / f  ->  (1 - uz/ur) / (1 - cr/cz)
+        out["clock_bound_share"] = max(0.0, min(1.0, (1.0 - uz / ur) / (1.0 - cr / cz))) if cz > cr * 1.02 else None
+    share = out.get("clock_bound_share")
+    if share is None:
+        out["reading"] = "the clock did not move between the legs: no statement"
+    elif share < 0.35:
+        out["reading"] = ("mostly NOT clock-bound: with the clock %.0f %% higher on zero data the launch is only %.1f %% shorter, so neither the "
+                          "power cap nor instruction issue sets most of its time; the memory side and the launch's ramp and uneven finish do "
+                          "(in-kernel stamps: profiles/r03_limiter.txt)" % ((cz / cr - 1) * 100, (1 - uz / ur) * 100))
+    else:
+        out["reading"] = ("clock-bound share %.2f: with the clock %.0f %% higher on zero data the launch is %.1f %% shorter -- the power cap "
+                          "(through the clock it allows) sets a large part of its time" % (share, (cz / cr - 1) * 100, (1 - uz / ur) * 100))
+    return out
 
 
 def time_reference_mode(_capi, get_window, xs, n_clips, dev, stream, secs=0.4):

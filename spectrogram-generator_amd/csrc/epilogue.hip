@@ -4,6 +4,7 @@
 #include "spectro_internal.h"
 
 #include <cstdint>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -321,67 +322,79 @@ inline int after_launch(const char* what) {
 
 }  // namespace
 
-// Scratch for the partials, one small buffer per (device, stream): launches on a stream are ordered, so successive
-// reductions on it may share the buffer.  Lives until the library is unloaded.
-void* reduction_scratch(hipStream_t s) {
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, void*> pool;
+// Everything the library keeps per (device, stream): launches on a stream are ordered, so successive calls on it may share
+//   * a small scratch for reduction partials (lives until the library is unloaded),
+//   * a workspace that grows on demand: the float copy of an int16 batch (sg_stft_i16 on rsmall / rbig plans), the chirp-z
+//     convolution buffers beyond LDS size.  Growing it synchronises THAT stream and frees the old block (include/spectro.h says
+//     so).  hipMallocAsync / hipFreeAsync around each call is NOT used ("A runtime finding").  Held until
+//     sg_workspace_release(),
+//   * one lock: a call that hands data from one launch to the next through any of the above SUBMITS its launches under it, so
+//     two host threads sharing a stream cannot interleave their sequences.  Calls on different streams or devices never
+//     wait for each other.
+namespace {
+struct StreamState {
+    std::recursive_mutex mu;
+    void* scratch = nullptr;
+    void* ws = nullptr; size_t ws_bytes = 0;
+};
+std::mutex g_streams_mu;
+std::map<std::pair<int, hipStream_t>, StreamState> g_streams;       // node addresses are stable
+
+StreamState* stream_state(hipStream_t s) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    void*& p = pool[{dev, s}];
-    if (!p && hipMalloc(&p, sizeof(double) * 16 * kMaxParts) != hipSuccess) p = nullptr;
-    return p;
+    std::lock_guard<std::mutex> lock(g_streams_mu);
+    return &g_streams[{dev, s}];
 }
-
-// Larger per-(device, stream) workspace that grows on demand: the float copy of an int16 batch (sg_stft_i16 on rsmall / rbig plans),
-// the chirp-z convolution buffers beyond LDS size.  Work on one stream is ordered, so successive calls share it; growing frees
-// the old block (hipFree waits for the device).  hipMallocAsync / hipFreeAsync around each call looked like the natural tool and
-// is NOT used: on this ROCm build blocks from the stream-ordered pool came back with stretches of another allocation's data
-// in ~8 % of int16 batch calls (tools/repro_i16.py; plain hipMalloc: none in 150).  Held until sg_workspace_release().
-namespace {
-struct Workspace { void* ptr = nullptr; size_t bytes = 0; };
-std::mutex g_ws_mu;
-std::map<std::pair<int, hipStream_t>, Workspace> g_ws;
 }  // namespace
 
-std::recursive_mutex& launch_sequence_mutex() {
-    static std::recursive_mutex mu;
-    return mu;
+std::recursive_mutex& launch_sequence_mutex(hipStream_t s) {
+    static std::recursive_mutex no_device;
+    StreamState* st = stream_state(s);
+    return st ? st->mu : no_device;
+}
+
+void* reduction_scratch(hipStream_t s) {
+    StreamState* st = stream_state(s);
+    if (!st) return nullptr;
+    std::lock_guard<std::recursive_mutex> lock(st->mu);
+    if (!st->scratch && hipMalloc(&st->scratch, sizeof(double) * 16 * kMaxParts) != hipSuccess) { (void)hipGetLastError(); st->scratch = nullptr; }
+    return st->scratch;
 }
 
 void* stream_workspace(hipStream_t s, size_t bytes) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lock(g_ws_mu);
-    Workspace& w = g_ws[{dev, s}];
-    if (w.bytes < bytes) {
-        if (w.ptr) { (void)hipStreamSynchronize(s); (void)hipFree(w.ptr); w.ptr = nullptr; w.bytes = 0; }
+    StreamState* st = stream_state(s);
+    if (!st) return nullptr;
+    std::lock_guard<std::recursive_mutex> lock(st->mu);
+    if (st->ws_bytes < bytes) {
+        if (st->ws) { (void)hipStreamSynchronize(s); (void)hipFree(st->ws); st->ws = nullptr; st->ws_bytes = 0; }
         const size_t want = bytes + bytes / 4;
-        if (hipMalloc(&w.ptr, want) != hipSuccess) {
+        if (hipMalloc(&st->ws, want) != hipSuccess) {
             (void)hipGetLastError();
-            if (hipMalloc(&w.ptr, bytes) != hipSuccess) { (void)hipGetLastError(); w.ptr = nullptr; return nullptr; }
-            w.bytes = bytes;
+            if (hipMalloc(&st->ws, bytes) != hipSuccess) { (void)hipGetLastError(); st->ws = nullptr; return nullptr; }
+            st->ws_bytes = bytes;
         } else {
-            w.bytes = want;
+            st->ws_bytes = want;
         }
     }
-    return w.ptr;
+    return st->ws;
 }
 
 extern "C" int sg_workspace_release(void) {
-    std::lock_guard<std::mutex> lock(g_ws_mu);
-    for (auto& kv : g_ws) {
-        if (kv.second.ptr) {
+    std::lock_guard<std::mutex> lock(g_streams_mu);
+    for (auto& kv : g_streams) {
+        std::lock_guard<std::recursive_mutex> l2(kv.second.mu);
+        if (kv.second.ws) {
             int cur = 0;
             (void)hipGetDevice(&cur);
             (void)hipSetDevice(kv.first.first);
             (void)hipDeviceSynchronize();
-            (void)hipFree(kv.second.ptr);
+            (void)hipFree(kv.second.ws);
             (void)hipSetDevice(cur);
+            kv.second.ws = nullptr;
+            kv.second.ws_bytes = 0;
         }
     }
-    g_ws.clear();
     return SG_OK;
 }
 
@@ -402,7 +415,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 template <typename T>
 int minmax_t(const void* spec, int64_t n_frames, int n_bins, int k_lo, int k_hi, void* mm, hipStream_t s) {
-    std::lock_guard<std::recursive_mutex> seq(launch_sequence_mutex());
+    std::lock_guard<std::recursive_mutex> seq(launch_sequence_mutex(s));
     T* const parts = static_cast<T*>(reduction_scratch(s));
     if (!parts) { set_error("minmax: no scratch memory"); return SG_ERR_HIP; }
     bool flat;
@@ -605,7 +618,7 @@ int sg_band_totals(const void* spec_dev, int dtype, int64_t n_frames, int n_bins
     }
     auto s = static_cast<hipStream_t>(stream);
     if (n_frames == 0) { SG_HIP(hipMemsetAsync(sums_dev, 0, sizeof(double) * n_bands, s)); return SG_OK; }
-    std::lock_guard<std::recursive_mutex> seq(launch_sequence_mutex());
+    std::lock_guard<std::recursive_mutex> seq(launch_sequence_mutex(s));
     double* const parts = static_cast<double*>(reduction_scratch(s));
     if (!parts) { set_error("band_totals: no scratch memory"); return SG_ERR_HIP; }
     const unsigned g = grid_for((n_frames + kRowsPerStep - 1) / kRowsPerStep * 64, kMaxParts);

@@ -90,7 +90,7 @@ static int build_common_tables(sg_plan& p, const std::vector<double>& window) {
 }
 
 static void free_tables(sg_plan* p) {
-    void** ptrs[] = {&p->win_dev, &p->tw_dev, &p->r8_tw_dev, &p->bs_chirp_dev, &p->bs_filter_dev, &p->bs_tw_dev};
+    void** ptrs[] = {&p->win_dev, &p->tw_dev, &p->r8_tw_dev, &p->r8_win_dev, &p->bs_chirp_dev, &p->bs_filter_dev, &p->bs_tw_dev};
     for (void** q : ptrs) {
         if (*q) (void)hipFree(*q);
         *q = nullptr;
@@ -131,7 +131,7 @@ static int run_stft(const sg_plan* plan, StftArgs& a);
 // keep the LDS kernel's own int16 loads.
 static int run_converted(const sg_plan* plan, StftArgs& a) {
     const int64_t span = static_cast<int64_t>(a.n_clips - 1) * a.clip_stride + a.n_samples;
-    std::lock_guard<std::recursive_mutex> seq(launch_sequence_mutex());
+    std::lock_guard<std::recursive_mutex> seq(launch_sequence_mutex(a.stream));
     void* const work = stream_workspace(a.stream, static_cast<size_t>(span) * sizeof(float));
     if (!work) { set_error("sg_stft_i16: no memory for the %lld-sample float workspace", static_cast<long long>(span)); return SG_ERR_HIP; }
     int rc = convert_i16(static_cast<const int16_t*>(a.x), static_cast<float*>(work), span, a.stream);
@@ -452,7 +452,7 @@ int sg_stft_db(const sg_plan* plan, const float* x_dev, int64_t n_samples, int64
     if (n_clips > 1 && clip_stride < n_samples) { set_error("clip_stride < n_samples"); return SG_ERR_ARG; }
     const int64_t need = n_frames * (k_hi - k_lo + 1);
     if (n_clips > 1 && out_clip_stride < need) { set_error("out_clip_stride %lld < %lld", (long long)out_clip_stride, (long long)need); return SG_ERR_ARG; }
-    std::lock_guard<std::recursive_mutex> seq(launch_sequence_mutex());
+    std::lock_guard<std::recursive_mutex> seq(launch_sequence_mutex(s));
     void* parts = reduction_scratch(s);
     if (!parts) { set_error("sg_stft_db: no scratch memory"); return SG_ERR_HIP; }
     StftArgs a{};

@@ -36,6 +36,7 @@ struct sg_plan {
     void* win_dev = nullptr;     // nperseg reals of dtype
     void* tw_dev = nullptr;      // nfft/2 complex of dtype: exp(-2*pi*i*k/nfft), k < nfft/2
     void* r8_tw_dev = nullptr;   // R8X3: [18][64] (R8X3D: double2), RSMALL: [(R-1)+11][64] float2 per-lane twiddles
+    void* r8_win_dev = nullptr;  // R8X3: the window times sqrt(scale / 2) (psd) or sqrt(scale / 4) (magnitude), so that a wave's prologue is loads only
     // Bluestein tables (complex of dtype)
     int bs_len = 0;              // padded pow2 length L >= 2*nfft-1
     void* bs_chirp_dev = nullptr;   // b[n] = exp(-i*pi*n^2/nfft), n < nfft
@@ -66,9 +67,9 @@ int r8x3_grid_waves(const sg_plan& p, int64_t total_frames, bool mel = false);  
 // epilogue.hip: per-(device, stream) scratch of 256 KiB for reduction partials; fold of n (min, max) float pairs into mm[2]
 void* reduction_scratch(hipStream_t s);
 // Sequences of launches that hand data to each other through reduction_scratch / stream_workspace (partials -> fold, convert ->
-// transform) hold this lock while they are being SUBMITTED, so that two host threads using the same stream cannot interleave their
-// launches (the stream then runs each sequence back to back).  Recursive: a sequence may contain another.
-std::recursive_mutex& launch_sequence_mutex();
+// transform) hold the stream's lock while they are being SUBMITTED, so that two host threads using the same stream cannot interleave
+// their launches (the stream then runs each sequence back to back).  Recursive: a sequence may contain another.
+std::recursive_mutex& launch_sequence_mutex(hipStream_t s);   // one per (device, stream): other streams never wait
 void* stream_workspace(hipStream_t s, size_t bytes);   // grows on demand, per (device, stream); nullptr when out of memory
 int fold_minmax_f32(const float* parts, int n_parts, float* mm_dev, hipStream_t s);
 int launch_rsmall(const sg_plan& p, const StftArgs& a);

@@ -201,7 +201,7 @@ int launch_t(const sg_plan& p, const StftArgs& a) {
         const int64_t cap = static_cast<int64_t>(p.n_cu);
         if (n_wg > cap) n_wg = cap;
         const size_t bytes = static_cast<size_t>(n_wg) * p.bs_len * 2 * sizeof(T);
-        std::lock_guard<std::recursive_mutex> seq(launch_sequence_mutex());      // (growing the workspace and launching on it: one step)
+        std::lock_guard<std::recursive_mutex> seq(launch_sequence_mutex(a.stream));      // (growing the workspace and launching on it: one step)
         void* const work = stream_workspace(a.stream, bytes);
         if (!work) { set_error("stft_bluestein: no memory for the %zu-byte convolution workspace", bytes); return SG_ERR_HIP; }
         prm.work = static_cast<Cx<T>*>(work);

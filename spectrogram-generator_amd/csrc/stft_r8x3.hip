@@ -92,7 +92,7 @@ struct R8Params {
     int n_waves;           // waves in the grid; wave w owns g in [w*total/n_waves, (w+1)*total/n_waves)
     float* out;            // [clip][frame][513] (OUT_PSD / OUT_MAG), [clip][frame] (OUT_BAND), [clip][frame][k_hi-k_lo+1] (OUT_DB*)
     int64_t out_clip_stride;
-    const float2* win2;    // [512]  (w[2n], w[2n+1])
+    const float2* win2;    // [512]  (w[2n], w[2n+1]) * sqrt(scale / 2) or sqrt(scale / 4): sg_plan::r8_win_dev
     const float2* tw;      // [18][64]
     float scale;
     int k_lo, k_hi;        // OUT_BAND, OUT_DB_BAND
@@ -104,6 +104,9 @@ struct R8Params {
     const int* mel_first;      // [n_mels]     first item of band j
     const int* mel_count;      // [n_mels]     items of band j
     int n_mels, log_scale;
+#ifdef SG_R8_STAMP
+    unsigned long long* stamps;   // diagnostic build only (tools/limiter.py): [n_waves][16] clock stamps; no output depends on them
+#endif
 };
 
 // What a frame leaves in HBM.
@@ -166,6 +169,12 @@ __global__ __launch_bounds__(64 * kWavesPerWg, occupancy_for(OUT)) void stft1024
 
     const int lw = xcd_remap(blockIdx.x, gridDim.x) * kWavesPerWg + wave;     // logical wave index
     if (lw >= p.n_waves) return;
+#ifdef SG_R8_STAMP
+    // MI355X_MICROARCH.md, DVFS give-back item 6: shader-clock (s_memtime) and 100 MHz (s_memrealtime) stamps around the frame
+    // loop of a DIAGNOSTIC build (tools/build_variant.sh stamp ... -DSG_R8_STAMP=1), written to a buffer of their own
+    const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long st_c1 = 0, st_r1 = 0;
+#endif
 
     float2 w[8];
 #pragma unroll
@@ -193,14 +202,9 @@ __global__ __launch_bounds__(64 * kWavesPerWg, occupancy_for(OUT)) void stft1024
     const float2* const x3b = buf + (kM - lane);    // - 64*m
 
     // |X|^2 * q: q = scale/2 for the interior bins of a one-sided PSD (doubled), scale/4 for bins 0 and 512 and for every
-    // bin of a magnitude spectrum.  sqrt(q_in) rides on the window registers (16 multiplies per wave instead of 8 per
-    // frame); what is left per frame is the factor 1/2 on lane 0's bins 0 and 512 of a PSD.
-    const float q_in = MODE == 0 ? p.scale * 0.5f : p.scale * 0.25f;
-    {
-        const float sq = sqrtf(q_in);
-#pragma unroll
-        for (int a = 0; a < 8; ++a) { w[a].x *= sq; w[a].y *= sq; }
-    }
+    // bin of a magnitude spectrum.  sqrt(q) rides on the window table (build_r8x3_tables: no multiply here, so nothing in the
+    // prologue waits for a table before the first frame's samples are requested); what is left per frame is the factor 1/2 on
+    // lane 0's bins 0 and 512 of a PSD.
     const float r0 = (MODE == 0 && lane == 0) ? 0.5f : 1.0f;
     float vmin = INFINITY, vmax = -INFINITY;         // OUT_DB*: this lane's extrema of the dB values written
     const int row_len = DB ? p.k_hi - p.k_lo + 1 : (MEL ? p.n_mels : kBins);
@@ -257,6 +261,12 @@ __global__ __launch_bounds__(64 * kWavesPerWg, occupancy_for(OUT)) void stft1024
         float2 raw[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) raw[k] = load_pair<TIn, ALIGNED>(src + 128 * k);
+#ifdef SG_R8_STAMP
+        if (st_c1 == 0) {      // prologue over: tables in registers, first frame's samples here
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            st_c1 = __builtin_amdgcn_s_memtime(); st_r1 = __builtin_amdgcn_s_memrealtime();
+        }
+#endif
 
         // A3 + A4 on the frame held in a[] (reads only; the sample registers stay intact)
         auto prep = [&](float2 (&a)[8]) {
@@ -420,6 +430,21 @@ __global__ __launch_bounds__(64 * kWavesPerWg, occupancy_for(OUT)) void stft1024
         vmax = wave_max_f(vmax);
         if (lane == 0) p.mm_parts[lw] = make_float2(vmin, vmax);
     }
+#ifdef SG_R8_STAMP
+    if (p.stamps) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the last rows have left the wave
+        const unsigned long long st_c2 = __builtin_amdgcn_s_memtime(), st_r2 = __builtin_amdgcn_s_memrealtime();
+        unsigned int hw_id, xcc_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+        if (lane == 0) {
+            unsigned long long* q = p.stamps + static_cast<size_t>(lw) * 16;
+            q[0] = st_c0; q[1] = st_r0; q[2] = st_c1; q[3] = st_r1; q[4] = st_c2; q[5] = st_r2;
+            q[6] = static_cast<unsigned long long>(p.total_frames * (lw + 1) / p.n_waves - p.total_frames * lw / p.n_waves);
+            q[7] = (static_cast<unsigned long long>(xcc_id) << 32) | hw_id;
+        }
+    }
+#endif
 }
 
 template <typename TIn, bool ALIGNED, bool DETREND, int OUT, int H>
@@ -509,11 +534,14 @@ int launch_r8x3(const sg_plan& p, const StftArgs& a) {
     const int n_wg = (prm.n_waves + kWavesPerWg - 1) / kWavesPerWg;
     prm.out = static_cast<float*>(a.out);
     prm.out_clip_stride = a.out_clip_stride;
-    prm.win2 = static_cast<const float2*>(p.win_dev);
+    prm.win2 = static_cast<const float2*>(p.r8_win_dev);
     prm.tw = static_cast<const float2*>(p.r8_tw_dev);
     prm.scale = static_cast<float>(p.scale);
     prm.k_lo = a.k_lo;
     prm.k_hi = a.k_hi;
+#ifdef SG_R8_STAMP
+    if (const char* e = getenv("SPECTRO_R8_STAMP_PTR")) prm.stamps = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0));
+#endif
     int out = a.band_mode ? OUT_BAND : (p.mode == SG_MODE_PSD ? OUT_PSD : OUT_MAG);
     if (a.db_mode) {
         if (p.mode != SG_MODE_PSD || !a.mm_parts) { set_error("r8x3: dB image needs a psd plan and a partials buffer"); return SG_ERR_ARG; }
@@ -564,6 +592,16 @@ int build_r8x3_tables(sg_plan& p, const std::vector<double>& /*window*/) {
     }
     SG_HIP(hipMalloc(&p.r8_tw_dev, tw.size() * sizeof(float2)));
     SG_HIP(hipMemcpy(p.r8_tw_dev, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
+    // the window as the kernel wants it: times sqrt(q), q = scale / 2 (psd: interior bins doubled) or scale / 4 (magnitude), in float
+    // arithmetic (what the kernel itself did per wave until round 3: same roundings, same bits)
+    std::vector<float> w(kN);
+    SG_HIP(hipMemcpy(w.data(), p.win_dev, kN * sizeof(float), hipMemcpyDeviceToHost));
+    const float sc = static_cast<float>(p.scale);
+    const float sq = sqrtf(p.mode == SG_MODE_MAGNITUDE ? sc * 0.25f : sc * 0.5f);
+    for (float& v : w) v *= sq;
+    if (p.r8_win_dev) { (void)hipFree(p.r8_win_dev); p.r8_win_dev = nullptr; }
+    SG_HIP(hipMalloc(&p.r8_win_dev, kN * sizeof(float)));
+    SG_HIP(hipMemcpy(p.r8_win_dev, w.data(), kN * sizeof(float), hipMemcpyHostToDevice));
     return SG_OK;
 }
 
