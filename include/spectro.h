@@ -19,14 +19,18 @@
  *   - the caller owns every buffer; a plan owns only its device tables
  *     (window, twiddles).  Pointers named *_dev are device pointers of the
  *     current HIP device, `stream` is a hipStream_t passed as void* (NULL =
- *     the default stream).  No entry point synchronises unless it says so.
+ *     the default stream).  No entry point synchronises unless it says so; one exception by construction: a call that needs a
+ *     LARGER stream workspace than that stream has so far (int16 batches on nfft 256 / 512 / 2048 / 4096 plans, chirp-z sizes whose
+ *     convolution buffer does not fit the LDS) synchronises THAT stream once while the block is replaced -- later calls of the
+ *     same or a smaller size are asynchronous again.
  *   - spectra are FRAME-MAJOR on the device: out[clip][frame][bin]; the Python
  *     shim returns the transposed view [bin][frame] exactly like
  *     scipy/signal/_spectral_py.py:2153 (moveaxis of a frame-major result).
  *   - re-entrant per (plan, stream).  Besides the thread-local error string the library keeps per-(device, stream) scratch (a small
  *     reduction buffer, a workspace that grows on demand: sg_workspace_release) that the calls of a stream share in stream order;
  *     entry points that hand data from one launch to the next through it (min/max and band totals: partials -> fold; sg_stft_db;
- *     int16 batches: convert -> transform) submit their launches under one internal lock, so host threads may share a stream.
+ *     int16 batches: convert -> transform) submit their launches under that stream's lock, so host threads may share a stream;
+ *     calls on different streams or devices never wait for each other on the host.
  */
 #ifndef SPECTRO_H
 #define SPECTRO_H

@@ -348,6 +348,19 @@ StreamState* stream_state(hipStream_t s) {
 }
 }  // namespace
 
+int device_cu_count() {
+    static std::mutex mu;
+    static int cached[64];                 // 0 = not asked yet
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    std::lock_guard<std::mutex> lock(mu);
+    if (cached[dev] == 0) {
+        hipDeviceProp_t prop;
+        cached[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return cached[dev];
+}
+
 std::recursive_mutex& launch_sequence_mutex(hipStream_t s) {
     static std::recursive_mutex no_device;
     StreamState* st = stream_state(s);

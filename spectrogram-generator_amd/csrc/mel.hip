@@ -247,8 +247,7 @@ int sg_mel_sparse(const float* spec_dev, int64_t n_frames, int n_bins, const int
     if (n_frames == 0) return SG_OK;
     if (!spec_dev || !mel_dev || !item_start_dev || !item_w_dev || !band_first_dev || !band_count_dev) { set_error("null device pointer"); return SG_ERR_ARG; }
     MelSparseParams prm{spec_dev, n_frames, n_bins, n_mels, log_scale, item_start_dev, item_w_dev, band_first_dev, band_count_dev, mel_dev};
-    int dev = 0, n_cu = 256;
-    if (hipGetDevice(&dev) == hipSuccess) { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount; }
+    const int n_cu = device_cu_count();
     auto s = static_cast<hipStream_t>(stream);
     int rc;
     switch (items_per_lane) {

@@ -184,7 +184,12 @@ def device_pool_clear():
 
 
 class DeviceBuffer:
-    """Owning handle of raw device memory obtained through sg_malloc (recycled through the pool above)."""
+    """Owning handle of raw device memory obtained through sg_malloc (recycled through the pool above).
+
+    Rule of the pool: a parked block may be handed to the next caller at once, and that caller's work runs on the DEFAULT stream.  A
+    buffer that was last used on another stream (``Plan.stft(..., stream=s)``, the pipelined path's non-blocking streams) must
+    therefore be freed with ``free(stream=s)``: the stream is synchronised before the block is parked.  ``free()`` without a stream
+    is for buffers used on the default stream only (``__del__`` parks that way as well)."""
 
     def __init__(self, nbytes: int):
         global _pool_bytes
@@ -205,10 +210,12 @@ class DeviceBuffer:
         check(rc)
         self.ptr = p.value
 
-    def free(self):
+    def free(self, stream=None):
         global _pool_bytes
         if getattr(self, "ptr", None):
             ptr, self.ptr = self.ptr, None
+            if stream is not None:
+                lib().sg_stream_sync(C.c_void_p(stream))     # work queued on that stream may still touch the block
             if _POOL_MAX_BYTES:
                 with _pool_lock:
                     if _pool_bytes + self.capacity <= _POOL_MAX_BYTES:

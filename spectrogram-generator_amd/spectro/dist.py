@@ -188,8 +188,6 @@ def long_clip_spectrogram(x, fs=1.0, window=("tukey", .25), nperseg=None, noverl
     from .signal import resolve_segments, spectrogram
     if getattr(x, "ndim", None) != 1:                          # ndarray or np.memmap: only this rank's samples are touched
         raise ValueError("long_clip_spectrogram takes one 1-D recording")
-    if mode == "phase":
-        raise ValueError("mode 'phase' unwraps along the whole time axis and cannot be cut into shards")
     if world is None or rank is None:
         world, rank = world_info()
     win, nps = resolve_segments(window, nperseg, input_length=x.shape[-1])

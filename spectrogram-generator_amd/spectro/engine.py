@@ -169,20 +169,51 @@ class DeviceSpectrogram:
         return out
 
 
-def _features_from_band(band, dtype_code, n_clips, n_frames):
+class DeviceArray:
+    """A result left on the device: an owned ``DeviceBuffer`` plus shape and dtype.  ``torch.as_tensor(arr, device="cuda")`` views it
+    without a copy (``__cuda_array_interface__``); keep the object alive for as long as the view is used."""
+
+    def __init__(self, buf, shape, dtype):
+        self.buf, self.shape, self.dtype = buf, tuple(int(v) for v in shape), np.dtype(dtype)
+
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": self.shape, "typestr": self.dtype.str, "data": (int(self.buf.ptr), False), "version": 2, "strides": None}
+
+    def to_host(self):
+        out = np.empty(self.shape, self.dtype)
+        if out.size:
+            self.buf.download(out)
+            _capi.stream_sync()
+        return out
+
+    def free(self):
+        if self.buf is not None:
+            self.buf.free()
+            self.buf = None
+
+
+def _features_from_band(band, dtype_code, n_clips, n_frames, keep_on_device=False):
     dt = _np_dtype(dtype_code)
-    feats = np.empty((n_clips, n_frames, 2), dt)
-    if feats.size:
-        d = _capi.DeviceBuffer(feats.nbytes)
-        try:
-            # one launch for the batch; the diff restarts at every clip
+    shape = (n_clips, n_frames, 2)
+    nbytes = n_clips * n_frames * 2 * np.dtype(dt).itemsize
+    d = _capi.DeviceBuffer(max(nbytes, 8))
+    try:
+        if nbytes:                    # one launch for the batch; the diff restarts at every clip
             _capi.check(_capi.lib().sg_band_features_batch(C.c_void_p(band.ptr), dtype_code, n_clips, n_frames,
                                                            C.c_void_p(d.ptr), None))
+        if keep_on_device:
+            _capi.stream_sync()       # the caller may hand the block to another library's stream
+            arr, d = DeviceArray(d, shape, dt), None
+            return arr
+        feats = np.empty(shape, dt)
+        if nbytes:
             d.download(feats)
             _capi.stream_sync()
-        finally:
+        return feats
+    finally:
+        if d is not None:
             d.free()
-    return feats
 
 
 def _prepare(x, fs, window, nperseg, noverlap, nfft, detrend, scaling, mode):
@@ -364,9 +395,11 @@ class DeviceClips:
         return DeviceSpectrogram(out, self.code, self.n_clips, n_frames, n_bins, _capi.freqs(nfft, fs),
                                  _capi.times(self.n_samples, nperseg, hop, fs), fs, plan, (self.n_clips,))
 
-    def band_log_power(self, fs, nperseg, hop, fmin, fmax, window=("tukey", .25), detrend="constant", clip_range=None):
+    def band_log_power(self, fs, nperseg, hop, fmin, fmax, window=("tukey", .25), detrend="constant", clip_range=None,
+                       keep_on_device=False):
         """A11 for the whole batch (or clips ``clip_range = (a, b)`` of it) in two launches: fused band power (the spectra
-        never reach HBM) and log10 / first difference.  -> ``(t, feats[n_clips, n_frames, 2])``; ``(None, None)`` without frames."""
+        never reach HBM) and log10 / first difference.  -> ``(t, feats[n_clips, n_frames, 2])``; ``(None, None)`` without frames.
+        ``keep_on_device``: ``feats`` is a ``DeviceArray`` (the caller frees it) -- what a gather over RCCL wants."""
         plan, nperseg, hop, nfft = self._plan(fs, window, nperseg, hop, detrend)
         n_frames = plan.n_frames(self.n_samples)
         a, b = (0, self.n_clips) if clip_range is None else (int(clip_range[0]), int(clip_range[1]))
@@ -374,11 +407,11 @@ class DeviceClips:
             raise ValueError("clip_range outside the batch")
         if n_frames == 0 or b == a:
             return None, None
-        return self._band_log_power(plan, nperseg, hop, nfft, fs, fmin, fmax, n_frames, a, b - a)
+        return self._band_log_power(plan, nperseg, hop, nfft, fs, fmin, fmax, n_frames, a, b - a, keep_on_device)
 
-    def _band_log_power(self, plan, nperseg, hop, nfft, fs, fmin, fmax, n_frames, first, count):
+    def _band_log_power(self, plan, nperseg, hop, nfft, fs, fmin, fmax, n_frames, first, count, keep_on_device=False):
         view = _ClipView(self, first, count)
-        return view.band_log_power(plan, nperseg, hop, nfft, fs, fmin, fmax, n_frames)
+        return view.band_log_power(plan, nperseg, hop, nfft, fs, fmin, fmax, n_frames, keep_on_device)
     def log_image(self, fs, nperseg, hop, fmin, fmax, global_max, window=("tukey", .25), detrend="constant", rescale=True):
         """The log display of PlotEngine.py:126-131 for a caller-supplied ``global_max`` (:110), per batch:
         ``(f_band, t, image[n_clips, n_band, n_frames])`` with the min-max taken over the whole batch.
@@ -426,13 +459,18 @@ class _ClipView:
         self.count, self.n_samples, self.cdt, self.code = count, clips.n_samples, clips.cdt, clips.code
         self.ptr = clips._float_ptr() + first * clips.n_samples * np.dtype(clips.cdt).itemsize
 
-    def band_log_power(self, plan, nperseg, hop, nfft, fs, fmin, fmax, n_frames):
+    def band_log_power(self, plan, nperseg, hop, nfft, fs, fmin, fmax, n_frames, keep_on_device=False):
         f = _capi.freqs(nfft, fs)
         t = _capi.times(self.n_samples, nperseg, hop, fs)
         k_lo, k_hi = bin_range(f, fmin, fmax)
         if k_lo > k_hi:
             feats = np.zeros((self.count, n_frames, 2), self.cdt)
             feats[..., 0] = np.log10(self.cdt(0) + 1e-20)
+            if keep_on_device:
+                buf = _capi.DeviceBuffer(max(feats.nbytes, 8))
+                buf.upload(feats)
+                _capi.stream_sync()
+                return t, DeviceArray(buf, feats.shape, feats.dtype)
             return t, feats
         isz = np.dtype(self.cdt).itemsize
         band = _capi.DeviceBuffer(self.count * n_frames * isz)
@@ -448,7 +486,7 @@ class _ClipView:
                     spec.free()
             else:
                 plan.band_power(self.ptr, self.n_samples, self.n_samples, self.count, k_lo, k_hi, band.ptr, n_frames)
-            return t, _features_from_band(band, self.code, self.count, n_frames)
+            return t, _features_from_band(band, self.code, self.count, n_frames, keep_on_device)
         finally:
             band.free()
 

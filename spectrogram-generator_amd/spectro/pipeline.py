@@ -102,17 +102,18 @@ class _Workspace:
         for k in range(2):
             if self.d_in[k] is None or self.d_in[k].nbytes < in_bytes:
                 if self.d_in[k] is not None:
-                    self.d_in[k].free()
+                    self.d_in[k].free(stream=self.streams[k].value)        # last used on stream k (DeviceBuffer's pool rule)
                 self.d_in[k] = _capi.DeviceBuffer(in_bytes)
             if self.d_out[k] is None or self.d_out[k].nbytes < out_bytes:
                 if self.d_out[k] is not None:
-                    self.d_out[k].free()
+                    self.d_out[k].free(stream=self.streams[k].value)
                 self.d_out[k] = _capi.DeviceBuffer(out_bytes)
         return self.streams, self.d_in, self.d_out
 
     def release(self):
         L = _capi.lib()
         for s in self.streams:
+            L.sg_stream_sync(s)                      # the blocks below were last used on these streams
             L.sg_stream_destroy(s)
         for b in self.d_in + self.d_out:
             if b is not None:

@@ -26,7 +26,7 @@ import numpy as np
 
 from . import dist as sdist
 
-__all__ = ["work_items", "clip_blocks", "hop_families", "sharded_sweep"]
+__all__ = ["work_items", "clip_blocks", "hop_families", "sweep_frames", "sharded_sweep"]
 
 
 def work_items(n_clips: int, n_samples: int, n_ffts: Sequence[int], hops: Sequence[int]):
@@ -94,18 +94,34 @@ def _default_compute(clips, fs, fmin, fmax, window):
     return run
 
 
-def _default_batch(fs, fmin, fmax, window):
+def sweep_frames(n_samples: int, n_fft: int, hop: int) -> int:
+    """Frames of one sweep item as the device call produces them: ``nperseg`` is clamped to the clip length like scipy does
+    (``_triage_segments``), the hop stays -- so ``n_fft > n_samples`` gives ONE frame, not none."""
+    nps = min(int(n_fft), int(n_samples))
+    return sdist.n_frames(n_samples, nps, hop) if nps > 0 else 0
+
+
+def _default_batch(fs, fmin, fmax, window, on_device=False):
     """``batch(host_clips[lo:hi]) -> runner(n_fft, hop, a, b) -> [b - a, n_frames] f32`` over clips ``a..b`` of that
-    upload; clips cross PCIe once per rank"""
+    upload; clips cross PCIe once per rank.  ``on_device``: the products stay in HBM as torch tensors (zero-copy views of the
+    library's blocks) -- what a gather over RCCL sends; otherwise they come back as numpy arrays."""
     from . import engine
 
     def open_batch(x):
         dev = engine.DeviceClips(x)
+        held = []                                           # device blocks behind tensors handed out
 
         def run(n_fft, hop, a, b):
-            t, feats = dev.band_log_power(fs, n_fft, hop, fmin, fmax, window=window, clip_range=(a, b))
+            t, feats = dev.band_log_power(fs, n_fft, hop, fmin, fmax, window=window, clip_range=(a, b), keep_on_device=on_device)
             if feats is None:
+                if on_device:
+                    import torch
+                    return torch.zeros((b - a, 0), dtype=torch.float32, device="cuda")
                 return np.zeros((b - a, 0), np.float32)
+            if on_device:
+                import torch
+                held.append(feats)
+                return torch.as_tensor(feats, device="cuda")[..., 0].to(torch.float32).contiguous()
             return np.ascontiguousarray(feats[..., 0], np.float32)
 
         def family(n_fft, g, members):
@@ -115,18 +131,25 @@ def _default_batch(fs, fmin, fmax, window):
             base = run(n_fft, g, a0, b0)
             out = []
             for hop, a, b in members:
-                nfr = sdist.n_frames(dev.n_samples, n_fft, hop)
-                out.append(np.ascontiguousarray(base[a - a0:b - a0, ::hop // g][:, :nfr]))
+                nfr = sweep_frames(dev.n_samples, n_fft, hop)
+                part = base[a - a0:b - a0, ::hop // g][:, :nfr]
+                out.append(part.contiguous() if on_device else np.ascontiguousarray(part))
             return out
+
+        def close():
+            for h in held:
+                h.free()
+            held.clear()
+            dev.free()
         run.family = family
-        run.close = dev.free
+        run.close = close
         return run
     return open_batch
 
 
 def sharded_sweep(clips, fs: float, n_ffts: Sequence[int], hops: Sequence[int], fmin: float = 0.0, fmax: float = 1e9,
                   window="hann", compute: Callable | None = None, dst: int = 0, batched: bool = True,
-                  batch_compute: Callable | None = None, share_hops: bool = True):
+                  batch_compute: Callable | None = None, share_hops: bool = True, device_products: bool | None = None):
     """Run the sweep on this rank's share and gather the reduced results on ``dst``.
 
     ``clips``: ``[n_clips, n_samples]`` host array, identical on every rank (each rank only touches its own share).
@@ -134,7 +157,9 @@ def sharded_sweep(clips, fs: float, n_ffts: Sequence[int], hops: Sequence[int], 
     hull it was given (default: log band power per frame through ``DeviceClips``); per item: ``compute(clip, n_fft, hop) -> 1-D float32`` (default: the same
     product, one call per item).  ``share_hops`` (batched form, runners that offer ``family``): hops of one n_fft that divide
     each other are served by one transform at their gcd and row subsampling (``hop_families``) -- identical values, cfg4's
-    15 pairs cost 5 transforms.  Returns on ``dst`` a dict ``{(clip, n_fft, hop): array}`` for ALL items, elsewhere None.
+    15 pairs cost 5 transforms.  ``device_products`` (default runner): the reduced products stay on the GPU until the gather has
+    moved them (default: yes under RCCL with more than one rank, where ``gather_to_root`` would otherwise stage host arrays
+    back onto the device).  Returns on ``dst`` a dict ``{(clip, n_fft, hop): array}`` for ALL items, elsewhere None.
     """
     import torch
     clips = np.asarray(clips)
@@ -157,40 +182,51 @@ def sharded_sweep(clips, fs: float, n_ffts: Sequence[int], hops: Sequence[int], 
     blocks = clip_blocks(n_clips, n_ffts, hops, world)
     lo = min(b[rank][0] for b in blocks.values())
     hi = max(b[rank][1] for b in blocks.values())
-    opener = batch_compute or _default_batch(fs, fmin, fmax, window)
+    if device_products is None:
+        device_products = world > 1 and "nccl" in sdist._backend()
+    on_device = bool(device_products) and batch_compute is None
+    opener = batch_compute or _default_batch(fs, fmin, fmax, window, on_device=on_device)
     run = opener(clips[lo:hi]) if hi > lo else None             # ONE upload: the hull of this rank's clip ranges
     done = {}
+
+    def as_tensor(v):
+        return v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(v, np.float32)))
     try:
         if run is not None and share_hops and hasattr(run, "family"):
             for n in dict.fromkeys(int(n) for n in n_ffts):
                 for g, fam in hop_families(hops):
                     members = [(h, blocks[(n, h)][rank][0] - lo, blocks[(n, h)][rank][1] - lo) for h in fam
                                if blocks[(n, h)][rank][1] > blocks[(n, h)][rank][0]]
-                    if len(members) > 1:                         # one transform at hop g for the whole family
-                        for (h, _, _), arr in zip(members, run.family(n, g, members)):
-                            done[(n, h)] = np.ascontiguousarray(np.asarray(arr, np.float32))
+                    if len(members) > 1 and n <= n_samples:      # one transform at hop g for the whole family (a clamped
+                        for (h, _, _), arr in zip(members, run.family(n, g, members)):     # nperseg shifts the hops: no sharing)
+                            done[(n, h)] = as_tensor(arr)
         mine = []
         for pair, ranges in blocks.items():
             c0, c1 = ranges[rank]
             if c1 <= c0:
-                mine.append(np.zeros((0, 0), np.float32))
+                mine.append(torch.zeros((0, 0), dtype=torch.float32))
             elif pair in done:
                 mine.append(done[pair])
             else:
-                mine.append(np.ascontiguousarray(np.asarray(run(pair[0], pair[1], c0 - lo, c1 - lo), np.float32)))   # one batched call
+                mine.append(as_tensor(run(pair[0], pair[1], c0 - lo, c1 - lo)))   # one batched call
+        # every rank can derive every shape: frames follow from (n_samples, n_fft, hop) -- with nperseg clamped to the clip length, as
+        # the device call clamps it -- and clips from the block table.  A product of another shape would leave the root waiting for
+        # bytes that never come (or a sender stuck): refuse it here, on every rank alike.
+        shapes = [[(ranges[r][1] - ranges[r][0], sweep_frames(n_samples, n, h)) if ranges[r][1] > ranges[r][0] else (0, 0)
+                   for (n, h), ranges in blocks.items()] for r in range(world)]
+        for m, want, pair in zip(mine, shapes[rank], blocks):
+            if tuple(m.shape) != tuple(want):
+                raise ValueError(f"sweep item {pair}: the product has shape {tuple(m.shape)}, the gather expects {tuple(want)}")
+        gathered = sdist.gather_to_root(mine, dst=dst, shapes=shapes)
     finally:
         if run is not None and hasattr(run, "close"):
             run.close()
-    # every rank can derive every shape: frames follow from (n_samples, n_fft, hop), clips from the block table
-    shapes = [[(ranges[r][1] - ranges[r][0], sdist.n_frames(n_samples, n, h)) if ranges[r][1] > ranges[r][0] else (0, 0)
-               for (n, h), ranges in blocks.items()] for r in range(world)]
-    gathered = sdist.gather_to_root([torch.from_numpy(m) for m in mine], dst=dst, shapes=shapes)
     if rank != dst and world > 1:
         return None
     out = {}
     for r, part in enumerate(gathered):
         for (pair, ranges), t in zip(blocks.items(), part):
-            arr = t.numpy()
+            arr = t.cpu().numpy()
             for j, clip in enumerate(range(*ranges[r])):
                 out[(clip, pair[0], pair[1])] = arr[j]
     return out

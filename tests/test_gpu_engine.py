@@ -553,5 +553,9 @@ def test_long_clip_cut_at_frame_boundaries_is_the_whole_call():
     x = rng.standard_normal(1024 + 3 * 896).astype(np.float32)
     parts = [long_clip_spectrogram(x, fs=1000.0, nperseg=1024, world=6, rank=r) for r in range(6)]
     assert [p[2].shape[-1] for p in parts] == [1, 1, 1, 1, 0, 0]
-    with pytest.raises(ValueError):
-        long_clip_spectrogram(x, nperseg=1024, mode="phase", world=2, rank=0)
+    # 'phase' unwraps along FREQUENCY (scipy:1003), frame by frame: frame shards of it are the whole call's columns as well
+    x = (rng.standard_normal(40000) * 0.2).astype(np.float64)
+    f, t, s = spectro.spectrogram(x, fs=8000.0, nperseg=256, noverlap=128, mode="phase")
+    parts = [long_clip_spectrogram(x, fs=8000.0, nperseg=256, noverlap=128, mode="phase", world=3, rank=r) for r in range(3)]
+    np.testing.assert_array_equal(np.concatenate([p[1] for p in parts]), t)
+    np.testing.assert_array_equal(np.concatenate([p[2] for p in parts], axis=-1), s)

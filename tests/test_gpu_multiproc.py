@@ -1,0 +1,188 @@
+"""Several processes / host threads on the REAL device path.
+
+* two ranks on one GPU over gloo (fresh child processes started by torch.distributed.run before this process touches the GPU in
+  them): the cfg4 job ``sharded_sweep`` through ``DeviceClips``, ``dist.global_max``, both deals -- rank 0 must hold exactly what a
+  single rank computes (``spectro/sweep.py``);
+* ``bench.py --gpus 2`` starting its own ranks (``SPECTRO_BENCH_SAME_GPU=1``: both on cuda:0, gloo for the barrier);
+* two host threads on two streams: neither waits for the other's stream on the host (per-stream launch lock), and their
+  reductions overlap on the device.
+
+No xGMI is involved here: a scaling curve on real links is the driver's 8-GPU run.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+import threading
+import time
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "spectrogram-generator_amd")
+
+pytestmark = pytest.mark.gpu
+
+SWEEP_SCRIPT = textwrap.dedent('''
+    import os, sys
+    sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+    import numpy as np, torch, torch.distributed as dist
+    dist.init_process_group("gloo")                      # RCCL refuses two ranks on one device; the data path is the same
+    from spectro import _capi, dist as sd, sweep, engine
+    _capi.ensure_device(0)                               # both ranks on cuda:0
+    world, rank = sd.world_info()
+    assert world == 2
+    clips = (np.random.default_rng(21).standard_normal((7, 30000)) * 0.2).astype(np.float32)
+    n_ffts, hops = [256, 1024, 2048], [64, 128, 256]
+    # a batch-global normalisation base (A9): all-reduce(MAX) of the per-shard maxima == the maximum of the whole batch
+    a, b = sd.shard_range(len(clips), world, rank)
+    dev = engine.stft(clips[a:b], fs=8000.0, nperseg=1024, window="hann", noverlap=768)
+    local = torch.tensor([float(dev.minmax(0, dev.n_bins - 1)[1])], dtype=torch.float64)
+    dev.free()
+    gmax = float(sd.global_max(local))
+    whole = engine.stft(clips, fs=8000.0, nperseg=1024, window="hann", noverlap=768)
+    assert gmax == float(whole.minmax(0, whole.n_bins - 1)[1]), "global_max over the shards != maximum of the batch"
+    whole.free()
+    # the sweep: batched deal with shared hops (default), batched without sharing, per-item deal
+    res = {name: sweep.sharded_sweep(clips, 8000.0, n_ffts, hops, fmin=100.0, fmax=3000.0, **kw)
+           for name, kw in (("shared", {}), ("plain", dict(share_hops=False)), ("items", dict(batched=False)))}
+    if rank == 0:
+        np.savez(sys.argv[3], **{f"{name}|{c}|{n}|{h}": v for name, r in res.items() for (c, n, h), v in r.items()})
+    else:
+        assert all(r is None for r in res.values())
+    dist.barrier(); dist.destroy_process_group()
+    os.write(1, ("rank %d ok" % rank + chr(10)).encode())
+''')
+
+
+def _free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def test_two_ranks_on_one_gpu_sweep_equals_single_rank(tmp_path):
+    script, out = tmp_path / "sweep2.py", tmp_path / "rank0.npz"
+    script.write_text(SWEEP_SCRIPT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), str(script), ROOT, PKG, str(out)],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+    # the single-rank result, computed here through the same entry point
+    sys.path.insert(0, PKG)
+    from spectro import sweep
+    clips = (np.random.default_rng(21).standard_normal((7, 30000)) * 0.2).astype(np.float32)
+    single = sweep.sharded_sweep(clips, 8000.0, [256, 1024, 2048], [64, 128, 256], fmin=100.0, fmax=3000.0)
+    got = np.load(out)
+    assert len(single) == 7 * 9
+    for (c, n, h), v in single.items():
+        for name in ("shared", "plain", "items"):
+            np.testing.assert_array_equal(got[f"{name}|{c}|{n}|{h}"], v, err_msg=f"{name} deal, item {(c, n, h)}")
+
+
+def test_bench_gpus_2_starts_its_own_ranks():
+    env = dict(os.environ, SPECTRO_BENCH_SAME_GPU="1", OMP_NUM_THREADS="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "5", "--clips", "16",
+                        "--settle-ms", "0", "--telemetry-s", "0", "--no-cpu-baseline", "--no-reference-mode", "--no-limiter-leg"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["clips_per_gpu"] == 16
+    assert d["config"]["frames_per_step_per_gpu"] == 16 * 1872
+    assert d["gather"]["band_power"]["values_ok"] is True
+    # value and the roofline fraction come from one clock: frac == value / n_gpus * 3076 B / 8 TB/s
+    assert abs(d["roofline"]["frac"] - d["value"] / 2 * 3076 / 8e12) < 1e-9
+    assert "traffic_source" in d["roofline"] and "us_per_launch_hip_events" in d["roofline"]
+
+
+def test_streams_do_not_wait_for_each_other():
+    """Stream A: ~60 ms of queued launches, then an int16 batch whose float workspace has to GROW -- the library synchronises stream A
+    inside that call, holding stream A's launch lock.  Stream B's reductions, submitted meanwhile from another thread, must neither
+    wait for that on the host (a process-wide lock made them wait) nor be kept off the device."""
+    import ctypes as C
+    import torch
+    sys.path.insert(0, PKG)
+    from spectro import _capi
+    from spectro.windows import get_window
+    _capi.ensure_device(0)
+    L = _capi.lib()
+    sA, sB = C.c_void_p(), C.c_void_p()
+    _capi.check(L.sg_stream_create(C.byref(sA)))
+    _capi.check(L.sg_stream_create(C.byref(sB)))
+    rng = np.random.default_rng(5)
+    n_clips, N = 64, 480000
+    plan = _capi.Plan(1024, 1024, 256, get_window("hann", 1024), 1, 48000.0, 0, 0, _capi.F32)
+    nfr = plan.n_frames(N)
+    x = _capi.DeviceBuffer(n_clips * N * 4)
+    x.upload((rng.standard_normal((n_clips, N)) * 0.1).astype(np.float32))
+    specA, specB = _capi.DeviceBuffer(n_clips * nfr * 513 * 4), _capi.DeviceBuffer(n_clips * nfr * 513 * 4)
+    mmB = _capi.DeviceBuffer(8)
+    plan.stft(x.ptr, N, N, n_clips, specB.ptr, nfr * 513)
+    _capi.stream_sync()
+    plan2k = _capi.Plan(2048, 2048, 512, get_window("hann", 2048), 1, 48000.0, 0, 0, _capi.F32)
+    small = (rng.standard_normal((8, 40000)) * 3000).astype(np.int16)
+    big = (rng.standard_normal((40, 40000)) * 3000).astype(np.int16)
+    d_small, d_big = _capi.DeviceBuffer(small.nbytes), _capi.DeviceBuffer(big.nbytes)
+    d_small.upload(small)
+    d_big.upload(big)
+    nf2 = plan2k.n_frames(40000)
+    o2 = _capi.DeviceBuffer(40 * nf2 * 1025 * 4)
+    _capi.stream_sync()
+    plan2k.stft(d_small.ptr, 40000, 40000, 8, o2.ptr, nf2 * 1025, stream=sA.value, int16=True)     # stream A's workspace exists now
+    _capi.stream_sync(sA.value)
+
+    extA, extB = torch.cuda.ExternalStream(sA.value), torch.cuda.ExternalStream(sB.value)
+    ev = {k: torch.cuda.Event(enable_timing=True) for k in ("ref", "a0", "a1", "b0", "b1")}
+    ev["ref"].record(extA)
+    started, times = threading.Event(), {}
+
+    def thread_a():
+        ev["a0"].record(extA)
+        for _ in range(700):                                              # ~60 ms of device work queued on stream A
+            plan.stft(x.ptr, N, N, n_clips, specA.ptr, nfr * 513, stream=sA.value)
+        started.set()
+        t0 = time.perf_counter()
+        plan2k.stft(d_big.ptr, 40000, 40000, 40, o2.ptr, nf2 * 1025, stream=sA.value, int16=True)   # grows the workspace: syncs A
+        times["a_blocked"] = time.perf_counter() - t0
+        ev["a1"].record(extA)
+        times["a_end"] = time.perf_counter()
+
+    def thread_b():
+        started.wait()
+        t0 = time.perf_counter()
+        ev["b0"].record(extB)
+        for _ in range(40):
+            _capi.check(L.sg_minmax(C.c_void_p(specB.ptr), _capi.F32, n_clips * nfr, 513, 0, 512, C.c_void_p(mmB.ptr), sB))
+        ev["b1"].record(extB)
+        _capi.stream_sync(sB.value)
+        times["b_wall"] = time.perf_counter() - t0
+        times["b_end"] = time.perf_counter()
+
+    ta, tb = threading.Thread(target=thread_a), threading.Thread(target=thread_b)
+    ta.start(); tb.start(); ta.join(); tb.join()
+    _capi.stream_sync(sA.value)
+    torch.cuda.synchronize()
+    a0, a1, b0, b1 = (ev["ref"].elapsed_time(ev[k]) for k in ("a0", "a1", "b0", "b1"))
+    mm = np.zeros(2, np.float32)
+    mmB.download(mm)
+    _capi.stream_sync()
+    for b in (x, specA, specB, mmB, d_small, d_big, o2):
+        b.free()
+    plan.close(); plan2k.close()
+    L.sg_stream_destroy(sA); L.sg_stream_destroy(sB)
+    assert np.isfinite(mm).all() and mm[1] > mm[0] >= 0
+    assert times["a_blocked"] > 0.02, f"stream A's growing call did not wait for its queue ({times['a_blocked'] * 1e3:.1f} ms): the test lost its premise"
+    # host side: B's 40 reductions (+ its own stream sync) took a fraction of what A sat blocked for, and were over before A returned
+    assert times["b_wall"] < 0.5 * times["a_blocked"], times
+    assert times["b_end"] < times["a_end"], times
+    # device side: the two sequences overlap in time
+    assert a0 < b1 and b0 < a1, (a0, a1, b0, b1)

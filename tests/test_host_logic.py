@@ -373,6 +373,29 @@ GLOO_SCRIPT = textwrap.dedent('''
         assert res_f.keys() == res.keys()
         for k in res:
             assert np.array_equal(res_f[k], res[k]), k
+    # n_fft beyond the clip length: the device call clamps nperseg to the clip (one frame), and so must the gather's shape table
+    short = (np.random.default_rng(11).standard_normal((3, 400)) * 0.1).astype(np.float32)
+    def open_clamped(xs):
+        def run(n, h, a, b):
+            nps = min(n, xs.shape[1])
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                f, t, s = orc.spectrogram(xs[a:b], fs=8000.0, nperseg=nps, window="hann", noverlap=nps - h)
+            return np.log10(s.sum(axis=-2) + 1e-20).astype(np.float32)
+        return run
+    assert sweep.sweep_frames(400, 512, 64) == 1 and sweep.sweep_frames(400, 256, 64) == 3 and sweep.sweep_frames(0, 256, 64) == 0
+    res_c = sweep.sharded_sweep(short, 8000.0, [256, 512], [64], batch_compute=open_clamped, dst=0)
+    if rank == 0:
+        assert len(res_c) == 6 and all(v.shape == ((1,) if k[1] == 512 else (3,)) for k, v in res_c.items())
+    # a product whose shape is not the one every rank derives is refused on every rank, before anything is sent
+    def open_wrong(xs):
+        return lambda n, h, a, b: np.zeros((b - a, 2), np.float32)
+    try:
+        sweep.sharded_sweep(short, 8000.0, [512], [64], batch_compute=open_wrong, dst=0)
+        raise SystemExit("a mis-shaped sweep product was not refused")
+    except ValueError:
+        pass
     dist.barrier(); dist.destroy_process_group()
     os.write(1, ("rank %d ok" % rank + chr(10)).encode())   # one write per rank: print() pieces of two ranks can interleave
 ''')
@@ -488,3 +511,25 @@ def test_c_client_builds_and_fails_loudly_without_a_gpu():
     assert r.returncode in (0, 3)
     if r.returncode == 3:
         assert "sg_init" in r.stderr and "no HIP device" in r.stderr
+
+
+def test_bench_spawns_its_own_ranks_and_refuses_a_wrong_world():
+    """bench.py --gpus N without a launcher starts N ranks itself (as a child process, before any GPU call); under a launcher whose
+    WORLD_SIZE differs from --gpus it exits non-zero instead of reporting another n_gpus.  No GPU needed for either check."""
+    import json
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "4", "--steps", "7", "--warmup", "2", "--dry-run-spawn"], capture_output=True,
+                       text=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    cmd = d["spawn"]
+    assert d["n_ranks"] == 4 and cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert os.path.samefile(cmd[cmd.index("--master-port") + 2], bench)
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]            # the ranks get the caller's arguments
+    # a launcher started 2 ranks but the line was asked for 8 GPUs
+    r = subprocess.run([sys.executable, bench, "--gpus", "8"], capture_output=True, text=True, timeout=120,
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+    assert not any(ln.startswith("{") for ln in r.stdout.splitlines())
