@@ -28,7 +28,10 @@ namespace {
 
 using namespace wavefft;
 
-constexpr int kS1 = 72, kS2 = 66, kSlab = 8 * kS1, kWaves = 4;
+#ifndef SG_RSMALL_WPW
+#define SG_RSMALL_WPW 4
+#endif
+constexpr int kS1 = 72, kS2 = 66, kSlab = 8 * kS1, kWaves = SG_RSMALL_WPW;
 
 struct SmallParams {
     const float* x;
@@ -180,9 +183,8 @@ __global__ __launch_bounds__(64 * kWaves) void stft_rsmall_kernel(const SmallPar
         if (SG_RSMALL_PRIO) __builtin_amdgcn_s_setprio(3);
         const int f = fg + g3;
         const bool live = f < p.n_frames;
-        float* const orow = p.out + static_cast<int64_t>(clip) * p.out_clip_stride +
-                            static_cast<int64_t>(min(f, p.n_frames - 1)) * (MODE == 2 ? 1 : NB);
         float bsum = 0.f;
+        float pk[4], pm[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const float2 A = a[t];
@@ -192,28 +194,44 @@ __global__ __launch_bounds__(64 * kWaves) void stft_rsmall_kernel(const SmallPar
             const float2 D = make_float2(A.x - B.x, A.y + B.y);
             const float2 T = make_float2(fmaf(cs.y, D.x, -cs.x * D.y), fmaf(cs.x, D.x, cs.y * D.y));
             const float2 Xk = csub(S, T), Xm = cadd(S, T);
-            float pk = fmaf(Xk.x, Xk.x, Xk.y * Xk.y);
-            float pm = fmaf(Xm.x, Xm.x, Xm.y * Xm.y);
-            if (MODE != 1 && t == 0) { pk *= r0; pm *= r0; }
-            if (MODE == 1) { pk = sqrtf(pk); pm = sqrtf(pm); }
+            pk[t] = fmaf(Xk.x, Xk.x, Xk.y * Xk.y);
+            pm[t] = fmaf(Xm.x, Xm.x, Xm.y * Xm.y);
+            if (MODE != 1 && t == 0) { pk[t] *= r0; pm[t] *= r0; }
+            if (MODE == 1) { pk[t] = sqrtf(pk[t]); pm[t] = sqrtf(pm[t]); }
             const int k = lu + L * t;
             if (MODE == 2) {
-                if (k >= p.k_lo && k <= p.k_hi) bsum += pk;
-                if (M - k >= p.k_lo && M - k <= p.k_hi) bsum += pm;
-            } else if (live) {
-                orow[k] = pk;
-                orow[M - k] = pm;
+                if (k >= p.k_lo && k <= p.k_hi) bsum += pk[t];
+                if (M - k >= p.k_lo && M - k <= p.k_hi) bsum += pm[t];
             }
         }
-        {
-            float pq = fmaf(a[4].x, a[4].x, a[4].y * a[4].y) * 4.0f;  // k = M/2 pairs with itself: lane lu == 0 holds Z[M/2]
-            if (MODE == 1) pq = sqrtf(pq);
-            if (MODE == 2) {
-                if (lu == 0 && M / 2 >= p.k_lo && M / 2 <= p.k_hi) bsum += pq;
-                bsum = group_sum<L>(bsum);
-                if (live && lu == 0) orow[0] = bsum;
-            } else if (live && lu == 0) {
-                orow[M / 2] = pq;
+        float pq = fmaf(a[4].x, a[4].x, a[4].y * a[4].y) * 4.0f;      // k = M/2 pairs with itself: lane lu == 0 holds Z[M/2]
+        if (MODE == 1) pq = sqrtf(pq);
+        if (MODE == 2) {
+            if (lu == 0 && M / 2 >= p.k_lo && M / 2 <= p.k_hi) bsum += pq;
+            bsum = group_sum<L>(bsum);
+            if (live && lu == 0) p.out[static_cast<int64_t>(clip) * p.out_clip_stride + f] = bsum;
+        } else {
+            // The G rows of a group are G * NB consecutive floats in HBM (consecutive frames of one clip).  A lane holds bins of ONE
+            // frame L apart, so storing from here writes G segments of 4L bytes per instruction, none of them aligned (a row is
+            // 4 * NB = 516 / 1028 bytes): twice the 64-byte write requests of a contiguous store.  The rows go through the slab
+            // instead (the split pass has read what it needs from it) and leave as G * NB consecutive floats, 256 bytes per
+            // instruction: nfft 256 / hop 64 127.7 -> see profiles/r03_rsmall_rows.txt.
+            wave_lds_fence();
+            float* const stage = reinterpret_cast<float*>(buf);
+            float* const mine = stage + g3 * NB + lu;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                mine[L * t] = pk[t];
+                stage[g3 * NB + M - lu - L * t] = pm[t];
+            }
+            if (lu == 0) stage[g3 * NB + M / 2] = pq;
+            wave_lds_fence();
+            const int n_live = min(G, p.n_frames - fg) * NB;            // (wave-uniform; a partial last group writes fewer rows)
+            float* const obase = p.out + static_cast<int64_t>(clip) * p.out_clip_stride + static_cast<int64_t>(fg) * NB;
+#pragma unroll
+            for (int i = 0; i < (G * NB + 63) / 64; ++i) {
+                const int idx = lane + 64 * i;
+                if (idx < n_live) obase[idx] = stage[idx];
             }
         }
         wave_lds_fence();
