@@ -42,6 +42,12 @@ static bool rbig_ok(const sg_plan& p) {
            (p.mode == SG_MODE_PSD || p.mode == SG_MODE_MAGNITUDE);
 }
 
+static bool rbigd_ok(const sg_plan& p) {
+    return p.dtype == SG_F64 && p.nperseg == p.nfft && (p.nfft == 2048 || p.nfft == 4096) &&
+           (p.detrend == SG_DETREND_NONE || p.detrend == SG_DETREND_CONSTANT) &&
+           (p.mode == SG_MODE_PSD || p.mode == SG_MODE_MAGNITUDE);
+}
+
 static bool stockham_ok(const sg_plan& p) {
     if (!is_pow2(p.nfft) || p.nfft < 2) return false;
     // LDS need of the largest case: one frame per workgroup, two nfft-real buffers + reduction scratch
@@ -166,6 +172,7 @@ static int run_stft(const sg_plan* plan, StftArgs& a) {
         case Kernel::R8X3D: return r8x3_f64_can_run(*plan, a) ? launch_r8x3_f64(*plan, a) : launch_stockham(*plan, a);
         case Kernel::RSMALL: return rsmall_can_run(*plan, a) ? launch_rsmall(*plan, a) : launch_stockham(*plan, a);
         case Kernel::RBIG: return rbig_can_run(*plan, a) ? launch_rbig(*plan, a) : launch_stockham(*plan, a);
+        case Kernel::RBIGD: return rbig_f64_can_run(*plan, a) ? launch_rbig_f64(*plan, a) : launch_stockham(*plan, a);
         case Kernel::STOCKHAM: return launch_stockham(*plan, a);
         case Kernel::BLUESTEIN: return launch_bluestein(*plan, a);
     }
@@ -305,6 +312,9 @@ int sg_plan_create(sg_plan** plan, int nperseg, int nfft, int hop, const double*
         } else if (rbig_ok(*p)) {
             p->kernel = Kernel::RBIG;
             rc = build_rbig_tables(*p);
+        } else if (rbigd_ok(*p)) {
+            p->kernel = Kernel::RBIGD;
+            rc = build_rbig_f64_tables(*p);
         } else if (stockham_ok(*p)) {
             p->kernel = Kernel::STOCKHAM;
         } else {
@@ -349,6 +359,7 @@ const char* sg_plan_kernel(const sg_plan* plan) {
         case Kernel::R8X3D: return plan->nfft == 1024 ? "r8x3d" : "rsmalld";
         case Kernel::RSMALL: return "rsmall";
         case Kernel::RBIG: return "rbig";
+        case Kernel::RBIGD: return "rbigd";
         case Kernel::STOCKHAM: return "stockham";
         case Kernel::BLUESTEIN: return "bluestein";
     }
@@ -379,6 +390,12 @@ int sg_plan_force_kernel(sg_plan* plan, const char* name) {
         if (!rbig_ok(*plan)) { set_error("plan cannot run on rbig"); return SG_ERR_UNSUPPORTED; }
         if (!plan->r8_tw_dev) { if (int rc = build_rbig_tables(*plan)) return rc; }
         plan->kernel = Kernel::RBIG;
+        return SG_OK;
+    }
+    if (!strcmp(name, "rbigd")) {
+        if (!rbigd_ok(*plan)) { set_error("plan cannot run on rbigd"); return SG_ERR_UNSUPPORTED; }
+        if (!plan->r8_tw_dev) { if (int rc = build_rbig_f64_tables(*plan)) return rc; }
+        plan->kernel = Kernel::RBIGD;
         return SG_OK;
     }
     if (!strcmp(name, "stockham")) {

@@ -19,7 +19,7 @@ int hip_fail(hipError_t e, const char* what);   // records message, returns SG_E
         if (e__ != hipSuccess) return ::sg::hip_fail(e__, #call);      \
     } while (0)
 
-enum class Kernel { R8X3, R8X3D, RSMALL, RBIG, STOCKHAM, BLUESTEIN };
+enum class Kernel { R8X3, R8X3D, RSMALL, RBIG, RBIGD, STOCKHAM, BLUESTEIN };
 
 }  // namespace sg
 
@@ -35,7 +35,7 @@ struct sg_plan {
     // device tables
     void* win_dev = nullptr;     // nperseg reals of dtype
     void* tw_dev = nullptr;      // nfft/2 complex of dtype: exp(-2*pi*i*k/nfft), k < nfft/2
-    void* r8_tw_dev = nullptr;   // R8X3: [18][64] (R8X3D: double2), RSMALL: [(R-1)+11][64] float2 per-lane twiddles
+    void* r8_tw_dev = nullptr;   // R8X3: [18][64] (R8X3D: double2), RSMALL: [(R-1)+11][64] float2, RBIG / RBIGD: [(R-1)+7+R/2][64] per-lane twiddles
     void* r8_win_dev = nullptr;  // R8X3: the window times sqrt(scale / 2) (psd) or sqrt(scale / 4) (magnitude), so that a wave's prologue is loads only
     // Bluestein tables (complex of dtype)
     int bs_len = 0;              // padded pow2 length L >= 2*nfft-1
@@ -77,6 +77,8 @@ int launch_rsmall(const sg_plan& p, const StftArgs& a);
 bool rsmall_can_run(const sg_plan& p, const StftArgs& a);
 int launch_rbig(const sg_plan& p, const StftArgs& a);
 bool rbig_can_run(const sg_plan& p, const StftArgs& a);
+int launch_rbig_f64(const sg_plan& p, const StftArgs& a);
+bool rbig_f64_can_run(const sg_plan& p, const StftArgs& a);
 int launch_stockham(const sg_plan& p, const StftArgs& a);
 int launch_bluestein(const sg_plan& p, const StftArgs& a);
 
@@ -84,6 +86,7 @@ int build_r8x3_tables(sg_plan& p, const std::vector<double>& window);
 int build_r8x3_f64_tables(sg_plan& p);
 int build_rsmall_tables(sg_plan& p);
 int build_rbig_tables(sg_plan& p);
+int build_rbig_f64_tables(sg_plan& p);
 int build_bluestein_tables(sg_plan& p);
 
 }  // namespace sg

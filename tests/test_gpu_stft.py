@@ -684,6 +684,71 @@ def test_rbig_kernel(sp, n, hop, detrend, mode):
     assert plan.kernel == "rbig"
 
 
+@pytest.mark.parametrize("n", [2048, 4096])
+@pytest.mark.parametrize("hop,detrend,mode,window", [(64, "constant", "psd", "hann"), (256, "constant", "psd", ("tukey", 0.25)),
+                                                     (1024, False, "magnitude", "hann"), (None, "constant", "psd", ("tukey", 0.25))])
+def test_rbig_f64_kernel(sp, n, hop, detrend, mode, window):
+    """The reference's nperseg 2048 / 4096 on float64 recordings (GUI.py:87-89, SweepManager.py:135-136): the double-precision
+    register kernel (stft_rbig_f64.hip) against the oracle, against the LDS kernel of the same plan, band power, edge clips, and the
+    fall-back for a clip the 16-byte loads cannot take."""
+    from spectro import _capi
+    from spectro.signal import plan_for
+    from spectro.windows import get_window
+    hop = n - n // 8 if hop is None else hop
+    rng = np.random.default_rng(n + hop)
+    N = n + hop * 23 + 6
+    N += N % 2
+    x = rng.standard_normal((5, N)) * 0.4 + 0.2
+    x[2] = 0.0
+    x[3] = -7.5
+    kw = dict(fs=48000.0, nperseg=n, window=window, noverlap=n - hop, detrend=detrend, mode=mode)
+    f, t, s = sp.spectrogram(x, **kw)
+    fo, to, so = orc.spectrogram(x, **kw)
+    np.testing.assert_array_equal(f, fo)
+    np.testing.assert_array_equal(t, to)
+    _check(s, so, np.float64)
+    if detrend:
+        assert np.all(s[2] == 0.0) and np.all(s[3] == 0.0)
+    plan = plan_for(get_window(window, n), n, n, hop, _capi.DETREND[detrend], 48000.0, 0, _capi.MODE[mode], _capi.F64)
+    assert plan.kernel == "rbigd"
+    nfr, nb = plan.n_frames(N), n // 2 + 1
+    d_in, d_a, d_b = _capi.DeviceBuffer(x.nbytes), _capi.DeviceBuffer(5 * nfr * nb * 8), _capi.DeviceBuffer(5 * nfr * nb * 8)
+    d_in.upload(x)
+    plan.stft(d_in.ptr, N, N, 5, d_a.ptr, nfr * nb)
+    plan.force_kernel("stockham")
+    try:
+        plan.stft(d_in.ptr, N, N, 5, d_b.ptr, nfr * nb)
+    finally:
+        plan.force_kernel("rbigd")
+    a, b = np.empty((5, nfr, nb)), np.empty((5, nfr, nb))
+    d_a.download(a)
+    d_b.download(b)
+    _capi.stream_sync()
+    _check(np.moveaxis(a, 1, 2), np.moveaxis(b, 1, 2), np.float64)
+    if mode == "psd":
+        d_bp = _capi.DeviceBuffer(5 * nfr * 8)
+        h = n // 2
+        for k_lo, k_hi in [(0, h), (3, 40), (h // 2, h // 2), (h // 2 - 1, h // 2 + 1), (0, 0), (h, h), (100, h - 1)]:
+            plan.band_power(d_in.ptr, N, N, 5, k_lo, k_hi, d_bp.ptr, nfr)
+            bp = np.empty((5, nfr))
+            d_bp.download(bp)
+            _capi.stream_sync()
+            ref_bp = a[:, :, k_lo:k_hi + 1].sum(-1)
+            assert np.all(np.abs(bp - ref_bp) <= 1e-12 * np.abs(a).max(axis=-1) * (k_hi - k_lo + 1) + 1e-300), (k_lo, k_hi)
+        d_bp.free()
+    # a clip that starts on an odd sample of the buffer (8-byte aligned only): the call falls back to the LDS kernel
+    plan.stft(d_in.ptr + 8, N - 1, N, 1, d_b.ptr, nfr * nb)
+    b1 = np.empty((plan.n_frames(N - 1), nb))
+    d_b.download(b1)
+    _capi.stream_sync()
+    _, _, so1 = orc.spectrogram(x[0, 1:], **kw)
+    _check(b1.T, so1, np.float64)
+    for buf in (d_in, d_a, d_b):
+        buf.free()
+    with pytest.raises(NotImplementedError):
+        plan_for(get_window("hann", 2048), 2048, 2048, 256, 1, 1.0, 0, 0, _capi.F32).force_kernel("rbigd")
+
+
 def test_random_shapes_property(sp):
     """Property test over random (N, nperseg, hop, dtype, detrend): shapes, bit-exact f/t and frame indexing, values vs
     the oracle.  Seeded (no hypothesis dependency on the GPU box); covers N < nperseg, odd and non power-of-two nperseg,

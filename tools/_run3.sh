@@ -1,5 +1,3 @@
 mkdir -p gpurun_out/r3
-for n in 256 512; do
-QB_ARGS="64 64 - $n" tools/pmc.sh rs${n} "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY" > gpurun_out/r3/pmc_rs${n}.txt 2>&1
-cat gpurun_out/r3/pmc_rs${n}.txt
-done
+timeout -k 10 600 python -m pytest tests/test_gpu_stft.py -x -q -m gpu -k "rbig or f64 or random_shapes" > gpurun_out/r3/pytest_rbigd.log 2>&1; echo "pytest rc=$?"; tail -8 gpurun_out/r3/pytest_rbigd.log
+for cfg in "64 2048 256" "64 2048 1792" "64 4096 256" "64 4096 3584" "64 2048 64"; do echo "== $cfg"; QB_SECS=0.5 timeout -k 10 200 python3 tools/quick_f64.py $cfg; done 2>&1 | tee gpurun_out/r3/quick_f64_rbigd.txt
