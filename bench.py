@@ -277,6 +277,8 @@ def main():
     for i in range(args.steps):
         step(i)
     ev1.record()
+    while not ev1.query():                            # poll instead of sleeping in the driver: the blocking synchronize below wakes
+        pass                                          # up tens of us late, which a 20-step region would book as kernel time
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
