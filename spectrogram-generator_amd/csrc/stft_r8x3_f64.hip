@@ -18,6 +18,9 @@
 //     in round 2: 202 / 864 / 443 us against 201 / 862 / 434 us per 64-clip batch at hops 256 / 64 / 128 -- the f64 arithmetic, not the
 //     re-read samples, is what this kernel's joules go to; not kept; of the fused products of the f32 kernel only the band power (A11: the HMM feature path on f64 recordings,
 //     `sg_stft_band_power`) is replicated here.
+//   * the rows of a group are stored straight from the split pass (G segments of 8L = 128 / 256 bytes per instruction at R = 2 / 4): sending
+//     them through the slab to leave as one contiguous run, what gave stft_rsmall.hip 13 % in round 3 (its segments are 64 bytes), costs
+//     this kernel 4-6 % (nfft 256 hop 64: 216 vs 208 us, 512 hop 128: 209 vs 197 us per 64-clip batch; same box, two rounds); not kept.
 // Algorithmic HBM bytes per frame: hop*8 + (nfft/2+1)*8 (band power: hop*8 + 8).
 #include "spectro_internal.h"
 
