@@ -169,7 +169,13 @@ for it in range(gcases):
     if rng.random() < 0.3:
         fmin = 0.0
     log_scale = bool(rng.random() < 0.6)
-    ok = True
+    ok, why = True, []
+
+    def chk(name, cond):
+        global ok
+        if not cond:
+            ok = False
+            why.append(name)
     try:
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
@@ -178,30 +184,38 @@ for it in range(gcases):
         gm = None if rng.random() < 0.5 else float(so.max() * rng.uniform(0.5, 3.0)) if so.size else None
         lf, lt, lsxx, img = orc.plot_image(fo, to, so, fmin, fmax, log_scale, gm)
         k_lo, k_hi = engine.bin_range(dev.f, fmin, fmax)
-        ok &= np.array_equal(dev.f, fo) and np.array_equal(dev.t, to) and (k_hi - k_lo + 1) == lf.size
+        chk("f/t/mask", np.array_equal(dev.f, fo) and np.array_equal(dev.t, to) and (k_hi - k_lo + 1) == lf.size)
         if lf.size and so.shape[-1]:
             tol = 1e-9 if f64 else 2e-4
             sl = dev.band_slice(k_lo, k_hi)
-            ok &= sl.shape == lsxx.shape and bool(np.all(np.abs(sl - lsxx) <= tol * np.abs(so).max() + 1e-300))
+            chk("band_slice", sl.shape == lsxx.shape and bool(np.all(np.abs(sl - lsxx) <= tol * np.abs(so).max() + 1e-300)))
             if f64 or not log_scale:                           # the f32 log image is ill-conditioned at its darkest bin (tests/test_gpu_db.py)
                 got = dev.image(k_lo, k_hi, log_scale, gm)
-                ok &= got.shape == img.shape and bool(np.abs(got - img).max() <= (1e-6 if f64 else 2e-4))
+                chk("image", got.shape == img.shape and bool(np.abs(got - img).max() <= (1e-6 if f64 else 2e-4)))
             feats = dev.features(k_lo, k_hi)
             lp = np.log10(lsxx.sum(axis=0) + 1e-20)
-            ok &= bool(np.allclose(np.asarray(feats)[..., 0].reshape(-1), lp, atol=1e-9 if f64 else 3e-5))
+            chk("features", bool(np.allclose(np.asarray(feats)[..., 0].reshape(-1), lp, atol=1e-9 if f64 else 3e-5)))
             bands = [(0.0, 4.0), (4.0, 8.0), (8.0, 13.0), (13.0, 30.0), (30.0, 80.0), (80.0, 250.0)]
             bp = orc.band_powers(lf, lsxx, {str(i): b for i, b in enumerate(bands)})
             ranges = [(int(np.searchsorted(lf, lo, "left")) + k_lo, int(np.searchsorted(lf, hi, "left")) + k_lo) for lo, hi in bands]
             tot = dev.band_totals([(k_lo, k_hi + 1)] + ranges)
             if tot[0] >= 1e-18:
-                ok &= bool(np.allclose(tot[1:] / tot[0], [bp[str(i)] for i in range(len(bands))], rtol=1e-9 if f64 else 1e-4, atol=1e-12))
+                # f32: a bin is good to 1e-4 of the frame's LARGEST bin, not of itself -- a band of one or
+                # two weak bins (case 157 of seed 3141: one 210-sample frame through the f32 chirp-z kernel) cannot be held to rtol 1e-4
+                want = np.array([bp[str(i)] for i in range(len(bands))])
+                got_r = np.asarray(tot[1:]) / tot[0]
+                if f64:
+                    chk("band_powers", bool(np.allclose(got_r, want, rtol=1e-9, atol=1e-12)))
+                else:
+                    n_el = np.array([max(hi - lo, 0) * lsxx.shape[-1] for lo, hi in ranges], np.float64)
+                    chk("band_powers", bool(np.all(np.abs(got_r - want) <= 1e-4 * np.abs(want) + 2e-4 * float(np.abs(so).max()) * n_el / tot[0] + 1e-12)))
         dev.free()
     except Exception as e:          # noqa: BLE001
         ok = False
         print("EXC", repr(e))
     if not ok:
         gbad += 1
-        print("GUI FAIL", it, dict(N=N, nperseg=nper, fs=fs, f64=bool(f64), band=(fmin, fmax), log_scale=log_scale))
+        print("GUI FAIL", it, why, dict(N=N, nperseg=nper, fs=fs, f64=bool(f64), band=(fmin, fmax), log_scale=log_scale))
 print(f"{gcases - gbad}/{gcases} GUI-flow cases agree with the oracle")
 
 # ---- streaming (cfg5): ragged chunks in, frames out == the offline call on the whole recording ----
