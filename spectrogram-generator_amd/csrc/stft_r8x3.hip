@@ -513,7 +513,7 @@ int r8x3_grid_waves(const sg_plan& p, int64_t total_frames, bool mel) {
     int occ = mel ? occupancy_for(OUT_MEL1) : kOccupancy;
     // short batches (the reference's own call: hop 896, 34 240 frames per 64 clips = 11 frames per wave at three waves per SIMD): two waves
     // per SIMD with runs half as long again are 2-5 % faster (32.3 vs 33.1-34.2 us, same box, two rounds; one wave: 42 us)
-    if (occ > 2 && total_frames < static_cast<int64_t>(p.n_cu) * 4 * occ * 14) occ = 2;
+    if (occ > 2 && total_frames > static_cast<int64_t>(p.n_cu) * 4 * occ && total_frames < static_cast<int64_t>(p.n_cu) * 4 * occ * 14) occ = 2;
     if (const char* e = getenv("SPECTRO_R8_OCC")) { const int v = atoi(e); if (v >= 1 && v <= kOccupancy) occ = v; }   // tuning aid
     int64_t n_waves = static_cast<int64_t>(p.n_cu) * 4 * occ;
     if (const char* e = getenv("SPECTRO_R8_WAVES")) { const long v = atol(e); if (v >= 64 && v <= 65536) n_waves = v; }          // tuning aid
