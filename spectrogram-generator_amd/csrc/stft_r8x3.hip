@@ -89,7 +89,10 @@ struct R8Params {
     int sub;               // hop * sub == 128 (hops 64, 32): a clip's frames are walked as `sub` interleaved sequences of hop 128
                            // (frames v, v + sub, v + 2 sub, ...), each of which slides its window in registers; 1 otherwise
     int64_t total_frames;  // n_frames * n_clips, flattened index g = clip * n_frames + j, j = position in that walk
-    int n_waves;           // waves in the grid; wave w owns g in [w*total/n_waves, (w+1)*total/n_waves)
+    int n_waves;           // waves in the grid; wave w owns run_len (+ 1 for w < run_rem) consecutive g, in wave order
+    int64_t run_len;       // total_frames / n_waves
+    int run_rem;           // total_frames % n_waves
+    double inv_n_frames;   // 1.0 / n_frames: a run's first (clip, position) by one multiply and a fix-up (see the kernel)
     float* out;            // [clip][frame][513] (OUT_PSD / OUT_MAG), [clip][frame] (OUT_BAND), [clip][frame][k_hi-k_lo+1] (OUT_DB*)
     int64_t out_clip_stride;
     const float2* win2;    // [512]  (w[2n], w[2n+1]) * sqrt(scale / 2) or sqrt(scale / 4): sg_plan::r8_win_dev
@@ -141,7 +144,7 @@ __device__ __forceinline__ float wave_max_f(float v) {
 // frame f+1 are issued before the FFT of frame f, which hides the HBM/L2 latency behind ~1000 VALU cycles.
 //
 // Work split: the grid is persistent (a few workgroups per CU); wave w owns a contiguous run of the flattened
-// (clip, frame) index space, runs differ by at most one frame, so there is no tail of half-empty rounds.
+// (clip, frame) index space, runs differ by at most one frame (the first total % n_waves waves hold the longer ones).
 // Window and twiddles stay in VGPRs (SG_TW_LDS=0, ~118 VGPRs = 4 waves/SIMD); SG_TW_LDS=1 moves the twiddles to a
 // 9 KiB workgroup-shared LDS table (83 VGPRs = 5 waves/SIMD).
 constexpr int occupancy_for(int out) { return out >= OUT_MEL1 ? (kOccupancy < 3 ? kOccupancy : 3) : kOccupancy; }   // OUT_MEL: +8*IPL weight registers
@@ -230,13 +233,21 @@ __global__ __launch_bounds__(64 * kWavesPerWg, occupancy_for(OUT)) void stft1024
         if (lane < kMelRow - kBins) mrow[kBins + lane] = 0.f;        // the slots behind bin 512 meet zero weights: keep them finite
     }
 
-    int64_t g = p.total_frames * lw / p.n_waves;
-    const int64_t g_end = p.total_frames * (lw + 1) / p.n_waves;
-    while (g < g_end) {                              // one iteration per clip touched by this run (1 or 2)
-        const int clip = static_cast<int>(g / p.n_frames);
-        const int f0 = static_cast<int>(g - static_cast<int64_t>(clip) * p.n_frames);
+    // This wave's run [g, g_end) of the flattened space, and the (clip, position in the clip's walk) it starts at -- without an integer
+    // division: the three 64-bit divisions this used to take are ~700 scalar instructions, and the three waves of a SIMD issue their
+    // scalar instructions one every four cycles between them: 3.5 us of a 3.6-3.9 us prologue (in-kernel stamps, profiles/r03_limiter.txt).
+    int64_t g = p.run_len * lw + min(lw, p.run_rem);
+    const int64_t g_end = g + p.run_len + (lw < p.run_rem ? 1 : 0);
+    int clip = static_cast<int>(static_cast<double>(g) * p.inv_n_frames);          // within one of the quotient: fixed up below
+    int pos;
+    {
+        int64_t r = g - static_cast<int64_t>(clip) * p.n_frames;
+        if (r < 0) { --clip; r += p.n_frames; } else if (r >= p.n_frames) { ++clip; r -= p.n_frames; }
+        pos = static_cast<int>(r);
+    }
+    while (g < g_end) {                              // one iteration per stretch: frames of one clip (and one sequence) that follow each other
+        const int f0 = pos;
         const int f1 = static_cast<int>(min(static_cast<int64_t>(p.n_frames), f0 + (g_end - g)));
-        g += f1 - f0;
 
         const TIn* const xclip = static_cast<const TIn*>(p.x) + static_cast<int64_t>(clip) * p.clip_stride + 2 * lane;
         // positions [f0, f1) of the clip's walk -> one stretch of one sequence: frames fs, fs + sub, ..., `count` of them
@@ -246,13 +257,16 @@ __global__ __launch_bounds__(64 * kWavesPerWg, occupancy_for(OUT)) void stft1024
             int v = 0, first = 0, len = (p.n_frames + p.sub - 1) / p.sub;
             while (f0 >= first + len) { first += len; ++v; len = (p.n_frames - v + p.sub - 1) / p.sub; }
             fs = (f0 - first) * p.sub + v;
-            count = min(f1 - f0, first + len - f0);
-            g -= (f1 - f0) - count;                         // the rest of [f0, f1) belongs to the next sequence: next trip
+            count = min(f1 - f0, first + len - f0);         // the rest of [f0, f1) belongs to the next sequence: next trip
         }
+        g += count;
+        pos += count;
+        const int clip_now = clip;
+        if (pos == p.n_frames) { pos = 0; ++clip; }        // the next stretch opens the next clip
         const int fstep = p.sub;
         // (OUT_DB_BAND: orow[k] is bin k's slot, i.e. the row start minus k_lo)
-        float* orow = BAND ? p.out + static_cast<int64_t>(clip) * p.out_clip_stride + fs
-                           : p.out + static_cast<int64_t>(clip) * p.out_clip_stride + static_cast<int64_t>(fs) * row_len -
+        float* orow = BAND ? p.out + static_cast<int64_t>(clip_now) * p.out_clip_stride + fs
+                           : p.out + static_cast<int64_t>(clip_now) * p.out_clip_stride + static_cast<int64_t>(fs) * row_len -
                                  (OUT == OUT_DB_BAND ? p.k_lo : 0);
         const int row_step = (BAND ? 1 : row_len) * fstep;
         const int src_step = p.hop * fstep;
@@ -440,7 +454,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg, occupancy_for(OUT)) void stft1024
         if (lane == 0) {
             unsigned long long* q = p.stamps + static_cast<size_t>(lw) * 16;
             q[0] = st_c0; q[1] = st_r0; q[2] = st_c1; q[3] = st_r1; q[4] = st_c2; q[5] = st_r2;
-            q[6] = static_cast<unsigned long long>(p.total_frames * (lw + 1) / p.n_waves - p.total_frames * lw / p.n_waves);
+            q[6] = static_cast<unsigned long long>(p.run_len + (lw < p.run_rem ? 1 : 0));
             q[7] = (static_cast<unsigned long long>(xcc_id) << 32) | hw_id;
         }
     }
@@ -534,6 +548,9 @@ int launch_r8x3(const sg_plan& p, const StftArgs& a) {
     prm.sub = 1;
     prm.total_frames = a.n_frames * a.n_clips;
     prm.n_waves = r8x3_grid_waves(p, prm.total_frames, a.mel_ipl > 0);
+    prm.run_len = prm.total_frames / prm.n_waves;
+    prm.run_rem = static_cast<int>(prm.total_frames % prm.n_waves);
+    prm.inv_n_frames = 1.0 / static_cast<double>(a.n_frames);
     const int n_wg = (prm.n_waves + kWavesPerWg - 1) / kWavesPerWg;
     prm.out = static_cast<float*>(a.out);
     prm.out_clip_stride = a.out_clip_stride;

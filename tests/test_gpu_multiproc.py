@@ -109,7 +109,6 @@ def test_streams_do_not_wait_for_each_other():
     inside that call, holding stream A's launch lock.  Stream B's reductions, submitted meanwhile from another thread, must neither
     wait for that on the host (a process-wide lock made them wait) nor be kept off the device."""
     import ctypes as C
-    import torch
     sys.path.insert(0, PKG)
     from spectro import _capi
     from spectro.windows import get_window
@@ -140,29 +139,22 @@ def test_streams_do_not_wait_for_each_other():
     plan2k.stft(d_small.ptr, 40000, 40000, 8, o2.ptr, nf2 * 1025, stream=sA.value, int16=True)     # stream A's workspace exists now
     _capi.stream_sync(sA.value)
 
-    extA, extB = torch.cuda.ExternalStream(sA.value), torch.cuda.ExternalStream(sB.value)
-    ev = {k: torch.cuda.Event(enable_timing=True) for k in ("ref", "a0", "a1", "b0", "b1")}
-    ev["ref"].record(extA)
     started, times = threading.Event(), {}
 
     def thread_a():
-        ev["a0"].record(extA)
         for _ in range(700):                                              # ~60 ms of device work queued on stream A
             plan.stft(x.ptr, N, N, n_clips, specA.ptr, nfr * 513, stream=sA.value)
         started.set()
         t0 = time.perf_counter()
         plan2k.stft(d_big.ptr, 40000, 40000, 40, o2.ptr, nf2 * 1025, stream=sA.value, int16=True)   # grows the workspace: syncs A
         times["a_blocked"] = time.perf_counter() - t0
-        ev["a1"].record(extA)
         times["a_end"] = time.perf_counter()
 
     def thread_b():
         started.wait()
         t0 = time.perf_counter()
-        ev["b0"].record(extB)
         for _ in range(40):
             _capi.check(L.sg_minmax(C.c_void_p(specB.ptr), _capi.F32, n_clips * nfr, 513, 0, 512, C.c_void_p(mmB.ptr), sB))
-        ev["b1"].record(extB)
         _capi.stream_sync(sB.value)
         times["b_wall"] = time.perf_counter() - t0
         times["b_end"] = time.perf_counter()
@@ -170,8 +162,6 @@ def test_streams_do_not_wait_for_each_other():
     ta, tb = threading.Thread(target=thread_a), threading.Thread(target=thread_b)
     ta.start(); tb.start(); ta.join(); tb.join()
     _capi.stream_sync(sA.value)
-    torch.cuda.synchronize()
-    a0, a1, b0, b1 = (ev["ref"].elapsed_time(ev[k]) for k in ("a0", "a1", "b0", "b1"))
     mm = np.zeros(2, np.float32)
     mmB.download(mm)
     _capi.stream_sync()
@@ -184,5 +174,7 @@ def test_streams_do_not_wait_for_each_other():
     # host side: B's 40 reductions (+ its own stream sync) took a fraction of what A sat blocked for, and were over before A returned
     assert times["b_wall"] < 0.5 * times["a_blocked"], times
     assert times["b_end"] < times["a_end"], times
-    # device side: the two sequences overlap in time
-    assert a0 < b1 and b0 < a1, (a0, a1, b0, b1)
+    # device side: B's stream was synchronised (its 40 reductions had RUN) while stream A still had tens of milliseconds of queued launches
+    # in front of the call thread A was blocked in -- the two streams' work overlapped on the device.  (No HIP events here: torch brings
+    # its own HIP runtime, and a second runtime initialised late in a long pytest process does not always see the GPU.)
+    assert times["a_end"] - times["b_end"] > 0.25 * times["a_blocked"], times
