@@ -33,6 +33,7 @@ from bench import Telemetry  # noqa: E402
 N, NFFT, HOP, NB = 480000, 1024, 256, 4
 BINS = NFFT // 2 + 1
 BPF = HOP * 4 + BINS * 4
+DT, ISZ, CODE = np.float32, 4, _capi.F32            # --nfft / --hop / --f64 replace these (any kernel family: the data leg only)
 
 
 def pct(v, q):
@@ -42,13 +43,13 @@ def pct(v, q):
 class Rig:
     def __init__(self, clips, n_sets=NB):
         self.clips = clips
-        self.plan = _capi.Plan(NFFT, NFFT, HOP, get_window("hann", NFFT), 1, 48000.0, 0, 0, _capi.F32)
+        self.plan = _capi.Plan(NFFT, NFFT, HOP, get_window("hann", NFFT), 1, 48000.0, 0, 0, CODE)
         self.nfr = self.plan.n_frames(N)
         self.frames = clips * self.nfr
         self.n_sets = n_sets
-        self.ins = [_capi.DeviceBuffer(clips * N * 4) for _ in range(n_sets)]
-        self.outs = [_capi.DeviceBuffer(clips * self.nfr * BINS * 4) for _ in range(n_sets)]
-        self.stamped = "stamp" in os.path.basename(os.path.dirname(_capi.LIB_PATH))
+        self.ins = [_capi.DeviceBuffer(clips * N * ISZ) for _ in range(n_sets)]
+        self.outs = [_capi.DeviceBuffer(clips * self.nfr * BINS * ISZ) for _ in range(n_sets)]
+        self.stamped = "stamp" in os.path.basename(os.path.dirname(_capi.LIB_PATH)) and self.plan.kernel == "r8x3"
         self.n_waves = 0
         if self.stamped:
             cu = _capi.device_info()["compute_units"]
@@ -61,13 +62,13 @@ class Rig:
         rng = np.random.default_rng(seed)
         for b, buf in enumerate(self.ins):
             if kind == "zeros":
-                _capi.check(_capi.lib().sg_memset(buf.ptr, 0, self.clips * N * 4, None))
+                _capi.check(_capi.lib().sg_memset(buf.ptr, 0, self.clips * N * ISZ, None))
             else:
                 chunk = 64
-                x = (rng.standard_normal((min(chunk, self.clips), N)) * 0.1).astype(np.float32)
+                x = (rng.standard_normal((min(chunk, self.clips), N)) * 0.1).astype(DT)
                 for c0 in range(0, self.clips, chunk):       # big batches: the same 64 clips repeated (values do not matter here)
                     n = min(chunk, self.clips - c0)
-                    _capi.check(_capi.lib().sg_memcpy_h2d(buf.ptr + c0 * N * 4, x.ctypes.data, n * N * 4, None))
+                    _capi.check(_capi.lib().sg_memcpy_h2d(buf.ptr + c0 * N * ISZ, x.ctypes.data, n * N * ISZ, None))
                 _capi.stream_sync()
         _capi.stream_sync()
 
@@ -140,7 +141,7 @@ def leg_data(rig, secs, out):
             us_sus = rig.sustained(secs)
             power = tel.stop(skip_s=min(0.6, secs / 2))
             us = rig.timed(400)
-            row = {"leg": "data", "rep": rep, "input": kind, "us_per_launch": us, "us_per_launch_sustained": us_sus,
+            row = {"leg": "data", "kernel": rig.plan.kernel, "nfft": NFFT, "hop": HOP, "rep": rep, "input": kind, "us_per_launch": us, "us_per_launch_sustained": us_sus,
                    "frac_of_8TBs": rig.frames * BPF / us / 8e6, "power": power}
             if rig.stamped:
                 samples = []
@@ -208,8 +209,17 @@ def main():
     ap.add_argument("--secs", type=float, default=2.0)
     ap.add_argument("--legs", default="data,duty,big")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--nfft", type=int, default=1024)
+    ap.add_argument("--hop", type=int, default=256)
+    ap.add_argument("--f64", action="store_true")
     ap.add_argument("--dump-stamps", default=None, help="diagnostic build: .npy of the raw stamps [launch][wave][8] of 6 launches (3 back to back, 3 after idle)")
     a = ap.parse_args()
+    global NFFT, HOP, BINS, BPF, DT, ISZ, CODE
+    NFFT, HOP = a.nfft, a.hop
+    BINS = NFFT // 2 + 1
+    if a.f64:
+        DT, ISZ, CODE = np.float64, 8, _capi.F64
+    BPF = HOP * ISZ + BINS * ISZ
     _capi.ensure_device()
     out = [{"lib": _capi.LIB_PATH, "device": _capi.device_info()}]
     print(json.dumps(out[0]), flush=True)
