@@ -267,7 +267,12 @@ def main():
             torch.cuda.synchronize(dev)
     for i in range(args.warmup):
         step(i)
+    # (the process's first event record costs ~65 us of one-time set-up -- tools/bench_overhead.py; keep it out of the timed region)
+    _e0, _e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    _e0.record()
+    _e1.record()
     torch.cuda.synchronize(dev)
+    _e0.elapsed_time(_e1)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
