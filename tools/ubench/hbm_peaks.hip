@@ -71,6 +71,29 @@ __global__ __launch_bounds__(256) void rows_k(const float* __restrict__ x, float
             for (int m = 0; m < 4; ++m) { row[lane + 64 * m] = s; row[512 - lane - 64 * m] = s; }
             row[256] = s;
         }
+    } else if (SHAPE >= 2) {
+        // round 3: the same per-row accesses, but the rows are dealt round-robin in runs of R = SHAPE rows (wave w takes runs w, w + n_waves,
+        // ...): at any moment the whole grid writes ONE compact window of n_waves * R rows instead of n_waves far-apart streams.  (Memory only: the
+        // STFT kernel would also have to reload its 8-block sample window at every run start.)
+        if (w >= n_waves) return;
+        constexpr int R = SHAPE;
+        const long n_runs = (n_rows + R - 1) / R;
+        for (long q = w; q < n_runs; q += n_waves) {
+            const long g0 = q * R, g1 = g0 + R < n_rows ? g0 + R : n_rows;
+            float2 v = *reinterpret_cast<const float2*>(x + g0 * 256 + 2 * lane);
+            float2 u = *reinterpret_cast<const float2*>(x + g0 * 256 + 128 + 2 * lane);
+            for (long f = g0; f < g1; ++f) {
+                const float s = v.x + v.y + u.x + u.y;
+                if (f + 1 < g1) {
+                    v = *reinterpret_cast<const float2*>(x + (f + 1) * 256 + 2 * lane);
+                    u = *reinterpret_cast<const float2*>(x + (f + 1) * 256 + 128 + 2 * lane);
+                }
+                float* row = out + f * 513;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) { row[lane + 64 * m] = s; row[512 - lane - 64 * m] = s; }
+                row[256] = s;
+            }
+        }
     } else {
         // workgroup b owns rows [n_rows*b/nb, n_rows*(b+1)/nb): reads them 16 B per lane, writes the 513/256-times larger
         // output span 16 B per lane, 4 accesses in flight
@@ -166,6 +189,8 @@ int main(int argc, char** argv) {
         printf("sustain %s: %.2f TB/s over %.1f s\n", argv[2], per * n / el / 1e12, el);
         return 0;
     }
+    const bool rows_only = argc > 1 && !strcmp(argv[1], "rows");     // ./hbm_peaks.bin rows: only the STFT row-pattern models
+    if (!rows_only) {
     sweep<0, v4f, 1>("read   16B x1", a4, b4, bytes, B);
     sweep<0, v4f, 4>("read   16B x4", a4, b4, bytes, B);
     sweep<0, v4f, 8>("read   16B x8", a4, b4, bytes, B);
@@ -185,7 +210,13 @@ int main(int argc, char** argv) {
     sweep<2, float, 16>("copy    4B x16 (r+w)", a1, b1, bytes, 2 * B);
     sweep<3, float, 4>("r1:w2   4B x4", a1, b1, bytes, 3 * B);
     sweep<3, float, 16>("r1:w2   4B x16", a1, b1, bytes, 3 * B);
+    }
     for (int occ : {1, 2, 4, 8}) rows<0>("stft rows: 2x8B in, 9x4B out/row", a1, b1, occ);
     for (int occ : {1, 2, 4, 8}) rows<1>("stft rows, 16B contiguous spans", a1, b1, occ);
+    for (int occ : {2, 3, 4}) rows<0>("stft rows (again, for the A/B)", a1, b1, occ);
+    for (int occ : {2, 3, 4}) rows<4>("stft rows, round-robin runs of 4", a1, b1, occ);
+    for (int occ : {2, 3, 4}) rows<8>("stft rows, round-robin runs of 8", a1, b1, occ);
+    for (int occ : {2, 3, 4}) rows<16>("stft rows, round-robin runs of 16", a1, b1, occ);
+    for (int occ : {2, 3, 4}) rows<32>("stft rows, round-robin runs of 32", a1, b1, occ);
     return 0;
 }
