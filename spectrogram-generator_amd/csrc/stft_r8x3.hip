@@ -53,7 +53,7 @@ constexpr int kWavesPerWg = SG_R8_WPW;
 #ifndef SG_R8_OCC
 // waves per SIMD the persistent grid fills.  The kernel needs 113 VGPRs, so four would fit; three are faster on every box
 // tried in round 2 (same-box A/B of two builds, 4 repetitions: 85.3-88.1 us against 88.0-90.4 us; two waves 93 us;
-// profiles/r02_ab_occupancy.txt): at the board power cap fewer, longer runs (39 frames instead of 29 per wave: fewer
+// profiles/r02_ab_occupancy.txt): fewer, longer runs (39 frames instead of 29 per wave: fewer row streams for the memory system, fewer
 // prologues, fewer halo re-reads) are worth more than the fourth wave's latency hiding.
 #define SG_R8_OCC (SG_TW_LDS ? 5 : 3)
 #endif

@@ -1,5 +1,6 @@
-// Energy price list: the headline kernel runs AT THE BOARD POWER CAP (1400 W, sclk 1.88 GHz: tools/telemetry.py), so
-// its time is energy / power and what an instruction costs in joules matters as much as its issue slots.
+// Energy price list.  The register kernels draw the board's full 1400 W on random data (sclk 1.6-2.1 GHz: tools/telemetry.py); round 3 measured
+// how much of their time follows that clock (profiles/r03_limiter_families.txt: little for the headline kernel, most for rbig 4096 and the f64
+// kernels) -- for those what an instruction costs in joules matters as much as its issue slots.
 // Each variant runs one instruction form back to back on every SIMD (4 waves/SIMD, register operands changing every
 // iteration -- not zeros) for `secs` seconds while tools/telemetry.py reads board power; it prints wave-instructions/s.
 // energy per wave-instruction = (P_variant - P_idle_loop) / rate.
