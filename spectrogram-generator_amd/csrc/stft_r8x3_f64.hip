@@ -32,7 +32,12 @@ namespace {
 
 constexpr int kS1 = 72, kS2 = 66, kSlab = 8 * kS1;       // 576 elements per plane
 constexpr int kWaves = 4;                                // per workgroup
-constexpr int kOcc = 2;                                  // waves per SIMD
+#ifndef SG_R8D_TW_LDS
+#define SG_R8D_TW_LDS 0        // 1: the t1 / t2 twiddles in a workgroup-shared LDS table instead of up to 56 VGPRs -> 142-152 VGPRs, three waves per
+                               // SIMD.  Measured (profiles/r03_f64_tw_lds.txt): nfft 1024 192 -> 210 us (the extra LDS reads cost more than the third
+                               // wave hides), 512 equal, 256 204 -> 200 us.  Off.
+#endif
+constexpr int kOcc = SG_R8D_TW_LDS ? 3 : 2;             // waves per SIMD
 #ifndef SG_R8D_PRIO
 // wave priority rises along a group (pass 1 -> stores), as in stft_r8x3.hip -- for the kernels that carry several frames per
 // wave only: same-box A/B per 64-clip batch, nfft 512 hop 128: 192 us with, 200-203 us without; nfft 1024 hop 256: 195-196 us
@@ -133,22 +138,38 @@ __global__ __launch_bounds__(64 * kWaves, kOcc) void stft_reg_f64_kernel(const R
     constexpr int G = 8 / R, M = 64 * R, L = 8 * R, NB = M + 1, RS = M + 8;
     constexpr bool kPrio = SG_R8D_PRIO && R < 8;
     static_assert(G * RS <= kSlab, "split regions must fit the slab");
-    __shared__ __attribute__((aligned(16))) double lds[kWaves * 2 * kSlab];
+    constexpr int kTwRows = SG_R8D_TW_LDS ? (R - 1 + 7) : 0;
+    __shared__ __attribute__((aligned(16))) double lds[kWaves * 2 * kSlab + 2 * kTwRows * 64 + 2];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const Slab sl{lds + wave * 2 * kSlab, lds + wave * 2 * kSlab + kSlab};
+    const Slab twl{lds + kWaves * 2 * kSlab, lds + kWaves * 2 * kSlab + kTwRows * 64};      // rows 0..R-2: t1, R-1..R+5: t2 (lane-linear)
+    if (SG_R8D_TW_LDS) {
+        for (int i = threadIdx.x; i < kTwRows * 64; i += 64 * kWaves) { const double2 v = p.tw[i]; twl.put(i, {v.x, v.y}); }
+        __syncthreads();
+    }
 
     const int lw = xcd_remap(blockIdx.x, gridDim.x) * kWaves + wave;
     if (lw >= p.n_waves) return;
 
-    cd w[R], t1[R - 1], t2[7], t3[4];
+    cd w[R], t3[4];
+#if !SG_R8D_TW_LDS
+    cd t1[R - 1], t2[7];
+#endif
     const double sq = sqrt(MODE != 1 ? p.scale * 0.5 : p.scale * 0.25);      // PSD scale rides on the window (stft_r8x3.hip)
 #pragma unroll
     for (int a = 0; a < R; ++a) { const double2 v = p.win2[lane + 64 * a]; w[a] = {v.x * sq, v.y * sq}; }
+#if SG_R8D_TW_LDS
+#define SG_T1(r) twl.get((r) * 64 + lane)
+#define SG_T2(s) twl.get((R - 1 + (s)) * 64 + lane)
+#else
 #pragma unroll
     for (int r = 0; r < R - 1; ++r) { const double2 v = p.tw[r * 64 + lane]; t1[r] = {v.x, v.y}; }
 #pragma unroll
     for (int s = 0; s < 7; ++s) { const double2 v = p.tw[(R - 1 + s) * 64 + lane]; t2[s] = {v.x, v.y}; }
+#define SG_T1(r) t1[r]
+#define SG_T2(s) t2[s]
+#endif
 #pragma unroll
     for (int t = 0; t < 4; ++t) { const double2 v = p.tw[(R - 1 + 7 + t) * 64 + lane]; t3[t] = {v.x, v.y}; }
 
@@ -201,7 +222,7 @@ __global__ __launch_bounds__(64 * kWaves, kOcc) void stft_reg_f64_kernel(const R
             // ---- pass 1: G independent R-point DFTs ----
             radix_first<R>(a + g * R);
 #pragma unroll
-            for (int r = 1; r < R; ++r) a[g * R + r] = cmul(a[g * R + r], t1[r - 1]);
+            for (int r = 1; r < R; ++r) a[g * R + r] = cmul(a[g * R + r], SG_T1(r - 1));
         }
 #pragma unroll
         for (int v = 0; v < 8; ++v) sl.put(x1w + 8 * v, a[v]);
@@ -213,7 +234,7 @@ __global__ __launch_bounds__(64 * kWaves, kOcc) void stft_reg_f64_kernel(const R
         if (kPrio) __builtin_amdgcn_s_setprio(1);
         radix8(a);
 #pragma unroll
-        for (int s = 1; s < 8; ++s) a[s] = cmul(a[s], t2[s - 1]);
+        for (int s = 1; s < 8; ++s) a[s] = cmul(a[s], SG_T2(s - 1));
 #pragma unroll
         for (int s = 0; s < 8; ++s) sl.put(x2w + R * s, a[s]);
         wave_lds_fence();
