@@ -326,7 +326,7 @@ inline int after_launch(const char* what) {
 //   * a small scratch for reduction partials (lives until the library is unloaded),
 //   * a workspace that grows on demand: the float copy of an int16 batch (sg_stft_i16 on rsmall / rbig plans), the chirp-z
 //     convolution buffers beyond LDS size.  Growing it synchronises THAT stream and frees the old block (include/spectro.h says
-//     so).  hipMallocAsync / hipFreeAsync around each call is NOT used (DESIGN.md section 5, "A runtime finding").  Held until
+//     so).  hipMallocAsync / hipFreeAsync around each call is NOT used (DESIGN.md section 5.5, "A runtime finding").  Held until
 //     sg_workspace_release(),
 //   * one lock: a call that hands data from one launch to the next through any of the above SUBMITS its launches under it, so
 //     two host threads sharing a stream cannot interleave their sequences.  Calls on different streams or devices never

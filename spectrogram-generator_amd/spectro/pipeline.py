@@ -2,7 +2,7 @@
 
 ``spectro.spectrogram`` on a batch is upload -> kernel -> download in sequence into a fresh ``np.empty``; for BASELINE cfg2
 (123 MB in, 246 MB out) that is 14 ms against a 0.09 ms kernel: 2.2 ms H2D, 4.4 ms D2H and ~7 ms of first-touch page
-faults while the DMA engine writes into never-touched pageable pages.  Here
+faults while the DMA engine writes into never-touched pageable pages (docs/LAB_NOTES.md section 5.1).  Here
 
   * the batch is cut into chunks of whole clips (~16 MB of input each) that alternate between TWO streams, each with its
     own device input / output buffers: chunk i+1's upload overlaps chunk i's download (PCIe is full duplex) and the kernel

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """int16 batches on rsmall / rbig plans against the float call on the same values (must be bit-identical): the reproducer that showed
-hipMallocAsync blocks carrying another allocation's data on this ROCm build (DESIGN.md section 5); prints the failing cases and their count.
+hipMallocAsync blocks carrying another allocation's data on this ROCm build (DESIGN.md section 5.5); prints the failing cases and their count.
 python tools/repro_i16.py"""
 import sys, numpy as np
 import os
