@@ -587,6 +587,8 @@ int launch_r8x3(const sg_plan& p, const StftArgs& a) {
     // hops 64, 32, 16: two / four / eight interleaved hop-128 sequences, so the window slides in registers (one 8-byte load per
     // lane and frame instead of eight); rows of one sequence are 2 / 4 / 8 rows apart in the output
     if (aligned && a.mel_ipl == 0 && (p.hop == 64 || p.hop == 32 || p.hop == 16) && !getenv("SPECTRO_R8_NO_SUB")) prm.sub = 128 / p.hop;
+    // tuning aid (tools/ab_sub.py): walk ANY hop as `sub` interleaved sequences, e.g. hop 256 as two hop-512 sequences whose rows alternate in the output
+    if (const char* e = getenv("SPECTRO_R8_SUB")) { const int v = atoi(e); if (aligned && a.mel_ipl == 0 && v >= 1 && v <= 8) prm.sub = v; }
     if (a.mel_ipl > 0 && !aligned) { set_error("r8x3: the mel form needs an even hop / clip stride and 8-byte aligned input"); return SG_ERR_UNSUPPORTED; }
     return launch_in<float>(prm, n_wg, a.stream, aligned, detrend, out);
 }
