@@ -95,7 +95,7 @@ int sg_memcpy2d(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, 
                 int kind, void* stream);
 int sg_memset(void* dst_dev, int value, size_t bytes, void* stream);
 int sg_stream_create(void** stream);
-int sg_stream_destroy(void* stream);
+int sg_stream_destroy(void* stream); /* synchronises the stream, frees the scratch / workspace the library kept for it */
 int sg_stream_sync(void* stream); /* blocks the caller */
 
 /* ---- plan ------------------------------------------------------------- */

@@ -393,6 +393,19 @@ void* stream_workspace(hipStream_t s, size_t bytes) {
     return st->ws;
 }
 
+// sg_stream_destroy: the stream's lock, reduction scratch and workspace go with it (the runtime may hand the same handle value to a
+// later stream; that one starts from an empty state).  The caller has synchronised the stream and no other thread is using it.
+void drop_stream_state(hipStream_t s) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    std::lock_guard<std::mutex> lock(g_streams_mu);
+    auto it = g_streams.find({dev, s});
+    if (it == g_streams.end()) return;
+    if (it->second.scratch) (void)hipFree(it->second.scratch);
+    if (it->second.ws) (void)hipFree(it->second.ws);
+    g_streams.erase(it);
+}
+
 extern "C" int sg_workspace_release(void) {
     std::lock_guard<std::mutex> lock(g_streams_mu);
     for (auto& kv : g_streams) {

@@ -278,7 +278,14 @@ int sg_stream_create(void** stream) {
     *stream = s;
     return SG_OK;
 }
-int sg_stream_destroy(void* stream) { if (stream) SG_HIP(hipStreamDestroy(static_cast<hipStream_t>(stream))); return SG_OK; }
+int sg_stream_destroy(void* stream) {
+    if (!stream) return SG_OK;
+    auto s = static_cast<hipStream_t>(stream);
+    SG_HIP(hipStreamSynchronize(s));
+    drop_stream_state(s);                      // its reduction scratch, workspace and launch lock (epilogue.hip)
+    SG_HIP(hipStreamDestroy(s));
+    return SG_OK;
+}
 int sg_stream_sync(void* stream) { SG_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream))); return SG_OK; }
 
 int sg_plan_create(sg_plan** plan, int nperseg, int nfft, int hop, const double* window, int detrend, double fs,

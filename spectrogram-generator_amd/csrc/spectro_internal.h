@@ -70,6 +70,7 @@ void* reduction_scratch(hipStream_t s);
 // transform) hold the stream's lock while they are being SUBMITTED, so that two host threads using the same stream cannot interleave
 // their launches (the stream then runs each sequence back to back).  Recursive: a sequence may contain another.
 std::recursive_mutex& launch_sequence_mutex(hipStream_t s);   // one per (device, stream): other streams never wait
+void drop_stream_state(hipStream_t s);                 // sg_stream_destroy: frees the stream's scratch + workspace, forgets its lock
 void* stream_workspace(hipStream_t s, size_t bytes);   // grows on demand, per (device, stream); nullptr when out of memory
 int device_cu_count();   // compute units of the current device, queried once per device (hipGetDeviceProperties costs 10s-100s of us)
 int fold_minmax_f32(const float* parts, int n_parts, float* mm_dev, hipStream_t s);

@@ -178,3 +178,50 @@ def test_streams_do_not_wait_for_each_other():
     # in front of the call thread A was blocked in -- the two streams' work overlapped on the device.  (No HIP events here: torch brings
     # its own HIP runtime, and a second runtime initialised late in a long pytest process does not always see the GPU.)
     assert times["a_end"] - times["b_end"] > 0.25 * times["a_blocked"], times
+
+
+def test_stream_destroy_releases_what_the_library_kept_for_it():
+    """The library keeps a reduction scratch and a workspace per (device, stream).  sg_stream_destroy must free them: a caller that
+    opens a stream per request would otherwise lose ~9 MB of HBM per request here (30 requests: ~270 MB)."""
+    import ctypes as C
+    sys.path.insert(0, PKG)
+    from spectro import _capi
+    from spectro.windows import get_window
+    _capi.ensure_device(0)
+    L = _capi.lib()
+    hip = C.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        f, t = C.c_size_t(), C.c_size_t()
+        assert hip.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+        return f.value
+
+    plan2k = _capi.Plan(2048, 2048, 512, get_window("hann", 2048), 1, 48000.0, 0, 0, _capi.F32)
+    x = (np.random.default_rng(9).standard_normal((40, 40000)) * 3000).astype(np.int16)
+    d_x = _capi.DeviceBuffer(x.nbytes)
+    d_x.upload(x)
+    nf = plan2k.n_frames(40000)
+    d_o, d_mm = _capi.DeviceBuffer(40 * nf * 1025 * 4), _capi.DeviceBuffer(8)
+    _capi.stream_sync()
+
+    def request():
+        s = C.c_void_p()
+        _capi.check(L.sg_stream_create(C.byref(s)))
+        plan2k.stft(d_x.ptr, 40000, 40000, 40, d_o.ptr, nf * 1025, stream=s.value, int16=True)       # converts into the stream's workspace
+        _capi.check(L.sg_minmax(C.c_void_p(d_o.ptr), _capi.F32, 40 * nf, 1025, 0, 1024, C.c_void_p(d_mm.ptr), s))   # uses its scratch
+        _capi.stream_sync(s.value)
+        mm = np.zeros(2, np.float32)
+        d_mm.download(mm)
+        _capi.stream_sync()
+        _capi.check(L.sg_stream_destroy(s))
+        return mm
+
+    first = request()
+    base = free_bytes()
+    for _ in range(30):
+        np.testing.assert_array_equal(request(), first)
+    lost = base - free_bytes()
+    for b in (d_x, d_o, d_mm):
+        b.free()
+    plan2k.close()
+    assert lost < 32 << 20, f"{lost / 2**20:.0f} MiB of device memory gone after 30 create / use / destroy cycles of a stream"
