@@ -72,6 +72,19 @@ def global_max(local_max):
     return local_max
 
 
+def all_agree(ok: bool) -> bool:
+    """True on every rank iff ``ok`` is True on every rank (all-reduce MIN; identity when not distributed): lets ranks refuse TOGETHER,
+    so that none of them walks into a collective the others have left."""
+    d = _dist()
+    world, _ = world_info()
+    if world == 1:
+        return bool(ok)
+    import torch
+    flag, _ = _comm_tensor(torch.tensor([1 if ok else 0], dtype=torch.int32))
+    d.all_reduce(flag, op=d.ReduceOp.MIN)
+    return bool(int(flag.cpu()[0]))
+
+
 def _backend():
     d = _dist()
     try:

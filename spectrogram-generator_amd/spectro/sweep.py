@@ -214,9 +214,10 @@ def sharded_sweep(clips, fs: float, n_ffts: Sequence[int], hops: Sequence[int], 
         # bytes that never come (or a sender stuck): refuse it here, on every rank alike.
         shapes = [[(ranges[r][1] - ranges[r][0], sweep_frames(n_samples, n, h)) if ranges[r][1] > ranges[r][0] else (0, 0)
                    for (n, h), ranges in blocks.items()] for r in range(world)]
-        for m, want, pair in zip(mine, shapes[rank], blocks):
-            if tuple(m.shape) != tuple(want):
-                raise ValueError(f"sweep item {pair}: the product has shape {tuple(m.shape)}, the gather expects {tuple(want)}")
+        bad = [(pair, tuple(m.shape), tuple(want)) for m, want, pair in zip(mine, shapes[rank], blocks) if tuple(m.shape) != tuple(want)]
+        if not sdist.all_agree(not bad):                     # every rank leaves here together, whichever of them holds the odd product
+            raise ValueError("sweep products do not have the shapes the gather expects" +
+                             (f": item {bad[0][0]} has {bad[0][1]}, expected {bad[0][2]}" if bad else " (on another rank)"))
         gathered = sdist.gather_to_root(mine, dst=dst, shapes=shapes)
     finally:
         if run is not None and hasattr(run, "close"):

@@ -396,6 +396,15 @@ GLOO_SCRIPT = textwrap.dedent('''
         raise SystemExit("a mis-shaped sweep product was not refused")
     except ValueError:
         pass
+    # ... also when only ONE rank holds the odd product: the others must not walk into the gather and wait there
+    def open_wrong_on_rank1(xs):
+        return lambda n, h, a, b: np.zeros((b - a, 2 if rank == 1 else 1), np.float32)
+    try:
+        sweep.sharded_sweep(short, 8000.0, [512], [64], batch_compute=open_wrong_on_rank1, dst=0)
+        raise SystemExit("rank %d went on although rank 1's product was mis-shaped" % rank)
+    except ValueError:
+        pass
+    assert sd.all_agree(True) and not sd.all_agree(rank == 0)
     dist.barrier(); dist.destroy_process_group()
     os.write(1, ("rank %d ok" % rank + chr(10)).encode())   # one write per rank: print() pieces of two ranks can interleave
 ''')
