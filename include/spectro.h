@@ -73,6 +73,8 @@ int sg_device_count(int* count);
 int sg_init(int device);
 /* name (e.g. "gfx950"), CU count and HBM bytes of the current device */
 int sg_device_info(char* arch, size_t arch_len, int* compute_units, uint64_t* hbm_bytes);
+/* free and total device memory of the current device right now (hipMemGetInfo): what a caller sizes its batches against */
+int sg_mem_info(uint64_t* free_bytes, uint64_t* total_bytes);
 /* PCI address of the current device as sysfs spells it ("0000:05:00.0"): /sys/bus/pci/devices/<id>/hwmon/ holds its
  * clock and board-power sensors, which bench.py reads beside the timing (the headline kernel runs at the power cap). */
 int sg_device_pci_bus_id(char* buf, size_t len /* >= 13 */);
@@ -145,8 +147,10 @@ int sg_stft(const sg_plan* plan, const void* x_dev, int64_t n_samples, int64_t c
  * Samples are used as-is (no 1/32768 scaling), i.e. like numpy's int16 -> float cast. */
 int sg_stft_i16(const sg_plan* plan, const int16_t* x_dev, int64_t n_samples, int64_t clip_stride,
                 int n_clips, float* out_dev, int64_t out_clip_stride, void* stream);
-/* Frees the per-stream workspaces the library keeps for int16 batches (float copy) and oversize chirp-z plans (they grow on
- * demand and are otherwise held until the library is unloaded).  Waits for the devices concerned. */
+/* Frees what the library keeps per (device, stream): the workspaces of int16 batches (float copy) and oversize chirp-z plans (they
+ * grow on demand) and the small reduction scratch.  Streams made by sg_stream_create lose theirs in sg_stream_destroy; for the
+ * default stream and for streams the caller owns this is the call (otherwise held until the library is unloaded).  Waits for the
+ * devices concerned; nothing may be in flight on other host threads. */
 int sg_workspace_release(void);
 /* dst[i] = (float)src[i], i < n: int16 PCM to the f32 the plans compute in (exact).  sg_stft_i16 does this itself where a
  * kernel has no int16 loads of its own (batches on nperseg 256 / 512 / 2048 / 4096: the stream's workspace, then the

@@ -410,15 +410,17 @@ extern "C" int sg_workspace_release(void) {
     std::lock_guard<std::mutex> lock(g_streams_mu);
     for (auto& kv : g_streams) {
         std::lock_guard<std::recursive_mutex> l2(kv.second.mu);
-        if (kv.second.ws) {
+        if (kv.second.ws || kv.second.scratch) {             // (the reduction scratch comes back on its next use)
             int cur = 0;
             (void)hipGetDevice(&cur);
             (void)hipSetDevice(kv.first.first);
             (void)hipDeviceSynchronize();
-            (void)hipFree(kv.second.ws);
+            if (kv.second.ws) (void)hipFree(kv.second.ws);
+            if (kv.second.scratch) (void)hipFree(kv.second.scratch);
             (void)hipSetDevice(cur);
             kv.second.ws = nullptr;
             kv.second.ws_bytes = 0;
+            kv.second.scratch = nullptr;
         }
     }
     return SG_OK;

@@ -219,6 +219,14 @@ int sg_device_info(char* arch, size_t arch_len, int* compute_units, uint64_t* hb
     return SG_OK;
 }
 
+int sg_mem_info(uint64_t* free_bytes, uint64_t* total_bytes) {
+    size_t f = 0, t = 0;
+    SG_HIP(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return SG_OK;
+}
+
 int sg_device_pci_bus_id(char* buf, size_t len) {
     if (!buf || len < 13) { set_error("sg_device_pci_bus_id: buffer of at least 13 bytes needed"); return SG_ERR_ARG; }
     int dev = 0;

@@ -30,6 +30,7 @@ SIGNATURES = {
     "sg_device_count": (_i, [C.POINTER(_i)]),
     "sg_init": (_i, [_i]),
     "sg_device_info": (_i, [C.c_char_p, _sz, C.POINTER(_i), C.POINTER(C.c_uint64)]),
+    "sg_mem_info": (_i, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "sg_device_pci_bus_id": (_i, [C.c_char_p, _sz]),
     "sg_malloc": (_i, [_pvp, _sz]),
     "sg_free": (_i, [_vp]),
@@ -145,6 +146,13 @@ def device_info():
     cu, mem = _i(0), C.c_uint64(0)
     check(lib().sg_device_info(buf, 64, C.byref(cu), C.byref(mem)))
     return {"arch": buf.value.decode(), "compute_units": cu.value, "hbm_bytes": mem.value}
+
+
+def mem_info():
+    """(free, total) bytes of the current device's memory right now"""
+    f, t = C.c_uint64(0), C.c_uint64(0)
+    check(lib().sg_mem_info(C.byref(f), C.byref(t)))
+    return f.value, t.value
 
 
 def device_pci_bus_id() -> str:
