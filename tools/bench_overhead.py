@@ -3,7 +3,7 @@
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "spectrogram-generator_amd"))
-import numpy as np, torch
+import torch
 from spectro import _capi
 from spectro.windows import get_window
 dev = torch.device("cuda", 0); torch.cuda.set_device(0); _capi.ensure_device(0)

@@ -5,7 +5,6 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "spectrogram-generator_amd"))
 import spectro
 from spectro import _capi, signal as sig
-from spectro.windows import get_window
 x = np.random.default_rng(0).standard_normal(16000)
 kw = dict(fs=16000.0, nperseg=512, scaling="density", mode="psd")
 for _ in range(20): spectro.spectrogram(x, **kw)

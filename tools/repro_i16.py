@@ -7,7 +7,6 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "spectrogram-generator_amd"))
 import spectro
-from oracle import stft_oracle as orc
 rng = np.random.default_rng(5)
 fails = 0
 for it in range(150):

@@ -5,7 +5,6 @@ A wave carries G = 8/R frames at once: lane j holds z_g[j + 64a] (a < R) for eve
 per lane like the 1024 kernel.  Pass 1 is an R-point DFT per frame, passes 2/3 are the radix-8 passes of
 stft_r8x3 with the register index v = g*R + r.  Design aid: checks the index maps and LDS bank behaviour."""
 import numpy as np
-import sys
 
 S1, S2 = 72, 66
 w8 = np.exp(-2j * np.pi * np.arange(8)[:, None] * np.arange(8)[None, :] / 8)
