@@ -93,6 +93,28 @@ class SpectroError(RuntimeError):
     pass
 
 
+def _share_torchs_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own ``libamdhip64.so`` and ask for it by that unversioned name, so a process that has
+    loaded libspectro.so first (against the system's ``libamdhip64.so.7``) gets a SECOND HIP / HSA runtime when torch is imported
+    later -- and the second one finds no GPU ("No HIP GPUs are available"), which would break ``spectro.dist`` / ``spectro.sweep``
+    for a caller who touched the engine before importing torch.  Loaded in this order instead -- torch's runtime first, by path --
+    the dynamic linker gives libspectro.so the same copy (its soname is the one libspectro.so needs), and torch finds it loaded.
+    ``SPECTRO_HIP_RUNTIME=system`` keeps the system runtime (processes that never import torch need nothing else)."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("SPECTRO_HIP_RUNTIME", "auto") == "system":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")           # locates the package without importing it
+        if spec is None or not spec.submodule_search_locations:
+            return
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except OSError:
+        pass                                               # torch's copy does not load here: the system runtime it is
+
+
 def lib():
     """Load libspectro.so once; raises ImportError with build instructions if it is absent."""
     global _lib
@@ -103,6 +125,7 @@ def lib():
                     raise ImportError(
                         f"{LIB_PATH} not found: build it with `python spectrogram-generator_amd/build.py` "
                         "(hipcc, gfx950).  There is no CPU fallback.")
+                _share_torchs_hip_runtime()
                 L = C.CDLL(LIB_PATH)
                 for name, (res, args) in SIGNATURES.items():
                     fn = getattr(L, name)       # AttributeError = header/library drift

@@ -222,3 +222,38 @@ def test_stream_destroy_releases_what_the_library_kept_for_it():
         b.free()
     plan2k.close()
     assert lost < 32 << 20, f"{lost / 2**20:.0f} MiB of device memory gone after 30 create / use / destroy cycles of a stream"
+
+
+IMPORT_ORDER_SCRIPT = textwrap.dedent('''
+    import os, sys
+    sys.path.insert(0, sys.argv[1])
+    import numpy as np
+    import spectro                                            # the engine FIRST ...
+    x = (np.random.default_rng(0).standard_normal(30000) * 0.1).astype(np.float32)
+    f, t, s = spectro.spectrogram(x, fs=8000.0, nperseg=1024, window="hann", noverlap=768)
+    import torch                                              # ... torch afterwards
+    assert torch.cuda.is_available(), "torch found no GPU after libspectro.so was loaded"
+    xt = torch.from_numpy(x).cuda()
+    from spectro import _capi
+    from spectro.windows import get_window
+    plan = _capi.Plan(1024, 1024, 256, get_window("hann", 1024), 1, 8000.0, 0, 0, _capi.F32)
+    nfr = plan.n_frames(30000)
+    out = torch.empty((nfr, 513), device="cuda", dtype=torch.float32)
+    plan.stft(xt.data_ptr(), 30000, 30000, 1, out.data_ptr(), nfr * 513, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().T, s), "the transform of torch's memory differs from the engine's own"
+    maps = sorted(set(l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l))
+    assert len(maps) == 1, maps
+    os.write(1, b"one runtime ok" + bytes([10]))
+''')
+
+
+def test_engine_before_torch_shares_one_hip_runtime(tmp_path):
+    """A caller that uses the engine and imports torch only later (spectro.dist / spectro.sweep do exactly that) must end up with ONE
+    HIP runtime in the process: PyTorch-ROCm bundles its own copy, and a second runtime sees no GPU (_capi._share_torchs_hip_runtime)."""
+    script = tmp_path / "order.py"
+    script.write_text(IMPORT_ORDER_SCRIPT)
+    env = dict(os.environ)
+    env.pop("SPECTRO_HIP_RUNTIME", None)
+    r = subprocess.run([sys.executable, str(script), PKG], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "one runtime ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
