@@ -104,6 +104,23 @@ def test_bench_gpus_2_starts_its_own_ranks():
     assert "traffic_source" in d["roofline"] and "us_per_launch_hip_events" in d["roofline"]
 
 
+def test_bench_gpus_2_strong_scaling_and_full_gather():
+    """--scaling strong shards ONE batch over the ranks; --gather-full moves the spectra to rank 0 by batched peer sends (gloo here)."""
+    env = dict(os.environ, SPECTRO_BENCH_SAME_GPU="1", OMP_NUM_THREADS="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--clips", "16",
+                        "--scaling", "strong", "--gather-full", "--settle-ms", "0", "--telemetry-s", "0", "--no-cpu-baseline",
+                        "--no-reference-mode", "--no-limiter-leg"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["clips_per_gpu"] == 8
+    assert d["gather"]["band_power"]["values_ok"] is True
+    full = d["gather"]["full_spectra"]
+    assert full["shapes_ok"] is True and full["bytes_to_root"] == 8 * 1872 * 513 * 4
+    assert abs(d["value"] - 16 * 1872 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]          # whole-job frames per step / step time
+
+
 def test_streams_do_not_wait_for_each_other():
     """Stream A: ~60 ms of queued launches, then an int16 batch whose float workspace has to GROW -- the library synchronises stream A
     inside that call, holding stream A's launch lock.  Stream B's reductions, submitted meanwhile from another thread, must neither
