@@ -34,6 +34,10 @@ constexpr int kS1 = 72, kS2 = 66;
 #ifndef SG_RBIG_PRIO
 #define SG_RBIG_PRIO 1          // wave priority rises along a frame (pass 1 -> stores), as in stft_r8x3; 0 = off
 #endif
+#ifndef SG_RBIG_TW2_REG
+#define SG_RBIG_TW2_REG 1          // the seven pass-2 twiddles in VGPRs where the occupancy has room (T = 4 sliding: 236 -> 254 of 256): 28 LDS reads fewer per
+                                   // frame; nfft 4096 hop 64 / 128 / 256: -0.3 / -1.3 / -2.4 % (profiles/r03_rbig_tw2_registers.txt); 0 = all from LDS
+#endif
 #ifndef SG_RBIG4_OCC
 #define SG_RBIG4_OCC 3            // waves per SIMD the T = 4 kernel is compiled for
 #endif
@@ -116,6 +120,12 @@ __global__ __launch_bounds__((64 * WavesFor<T, H>::value), (OccFor<T, H>::value)
     const float2* const x3b = buf + (256 - lane);            // - 64*(c - 4i)
 
     const float r0 = (MODE != 1 && lane == 0) ? 0.5f : 1.0f;
+    constexpr bool kTw2Reg = SG_RBIG_TW2_REG && T == 4 && H > 0;
+    float2 t2r[kTw2Reg ? 7 : 1];
+    if (kTw2Reg) {
+#pragma unroll
+        for (int s = 0; s < 7; ++s) t2r[s] = lds_get(t2 + 64 * s);
+    }
 
     // one frame: samples d[][] (destroyed) -> row orow
     auto frame = [&](float2 (&d)[T][8], float* const orow) {
@@ -181,7 +191,7 @@ __global__ __launch_bounds__((64 * WavesFor<T, H>::value), (OccFor<T, H>::value)
         for (int q = 0; q < T; ++q) {
             radix8(d[q]);
 #pragma unroll
-            for (int s = 1; s < 8; ++s) d[q][s] = cmul(d[q][s], lds_get(t2 + 64 * (s - 1)));
+            for (int s = 1; s < 8; ++s) d[q][s] = cmul(d[q][s], kTw2Reg ? t2r[kTw2Reg ? s - 1 : 0] : lds_get(t2 + 64 * (s - 1)));
         }
         float2 e[T][8];                                      // pass-3 operands: e[q3][j]
 #pragma unroll
