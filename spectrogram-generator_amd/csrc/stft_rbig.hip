@@ -29,6 +29,9 @@ namespace {
 using namespace wavefft;
 
 constexpr int kS1 = 72, kS2 = 66;
+typedef float v4f __attribute__((ext_vector_type(4)));
+// two neighbouring float2 of the tables in one 16-byte LDS read (volatile for the reason lds_get is, fft_wave.h)
+__device__ __forceinline__ v4f lds_get2(const float2* p) { return *(__attribute__((address_space(3))) volatile v4f*)(p); }
 // waves per workgroup (the LDS tables are shared by the workgroup): T = 4 -> one workgroup of 12 waves per CU
 // (43 KiB of tables + 12 x 4.5 KiB, 142 VGPRs = 3 waves/SIMD); T = 2 -> two workgroups of 8 (21 + 36 KiB each)
 #ifndef SG_RBIG_PRIO
@@ -37,6 +40,10 @@ constexpr int kS1 = 72, kS2 = 66;
 #ifndef SG_RBIG_TW2_REG
 #define SG_RBIG_TW2_REG 1          // the seven pass-2 twiddles in VGPRs where the occupancy has room (T = 4 sliding: 236 -> 254 of 256): 28 LDS reads fewer per
                                    // frame; nfft 4096 hop 64 / 128 / 256: -0.3 / -1.3 / -2.4 % (profiles/r03_rbig_tw2_registers.txt); 0 = all from LDS
+#endif
+#ifndef SG_RBIG_B128
+#define SG_RBIG_B128 1             // window, t1 and t3 tables keep rows 2m, 2m+1 of a lane side by side: one ds_read_b128 per two rows (a b128 read moves twice
+                                   // the bytes in 1.3x the time); -1 ... -2.7 % on every shape (profiles/r03_rbig_b128_tables.txt); 0 = one ds_read_b64 per row
 #endif
 #ifndef SG_RBIG4_OCC
 #define SG_RBIG4_OCC 3            // waves per SIMD the T = 4 kernel is compiled for
@@ -87,7 +94,7 @@ template <int T, bool DETREND, int MODE, int H>
 __global__ __launch_bounds__((64 * WavesFor<T, H>::value), (OccFor<T, H>::value)) void stft_rbig_kernel(const BigParams p) {
     constexpr int R = 8 * T, M = 64 * R, NB = M + 1, kWaves = WavesFor<T, H>::value;
     constexpr int kSlab = kSlabElems;                        // complex elements per wave
-    constexpr int kTw1 = M, kTw2 = kTw1 + (R - 1) * 64, kTw3 = kTw2 + 7 * 64, kTabs = kTw3 + (R / 2) * 64;
+    constexpr int kTw1 = M, kTw2 = kTw1 + (SG_RBIG_B128 ? R : R - 1) * 64, kTw3 = kTw2 + 7 * 64, kTabs = kTw3 + (R / 2) * 64;   // B128: t1 padded to an even row count
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -97,9 +104,22 @@ __global__ __launch_bounds__((64 * WavesFor<T, H>::value), (OccFor<T, H>::value)
     const float q_in = MODE != 1 ? p.scale * 0.5f : p.scale * 0.25f;
     {
         const float sq = sqrtf(q_in);
-        for (int i = threadIdx.x; i < M; i += 64 * kWaves) { const float2 wv = p.win2[i]; lds[i] = make_float2(wv.x * sq, wv.y * sq); }
+        for (int i = threadIdx.x; i < M; i += 64 * kWaves) {
+            const float2 wv = p.win2[i];
+            const int r = i >> 6, l = i & 63;                // row r of lane l; SG_RBIG_B128: rows 2m, 2m+1 of a lane side by side
+            lds[SG_RBIG_B128 ? (r >> 1) * 128 + 2 * l + (r & 1) : i] = make_float2(wv.x * sq, wv.y * sq);
+        }
     }
-    for (int i = threadIdx.x; i < kTabs - M; i += 64 * kWaves) lds[M + i] = p.tw[i];
+    for (int i = threadIdx.x; i < (R - 1 + 7 + R / 2) * 64; i += 64 * kWaves) {
+        const int r = i >> 6, l = i & 63;                    // p.tw: rows [0, R-1) t1, [R-1, R+6) t2, [R+6, ...) t3
+        int dst = M + i;
+        if (SG_RBIG_B128) {                                  // t1 and t3: rows 2m, 2m+1 of a lane side by side (one ds_read_b128); t2 as it was
+            if (r < R - 1) dst = kTw1 + (r >> 1) * 128 + 2 * l + (r & 1);
+            else if (r < R + 6) dst = kTw2 + (r - (R - 1)) * 64 + l;
+            else dst = kTw3 + ((r - (R + 6)) >> 1) * 128 + 2 * l + ((r - (R + 6)) & 1);
+        }
+        lds[dst] = p.tw[i];
+    }
     __syncthreads();
 
     const int lw = xcd_remap(blockIdx.x, gridDim.x) * kWaves + wave;
@@ -143,6 +163,16 @@ __global__ __launch_bounds__((64 * WavesFor<T, H>::value), (OccFor<T, H>::value)
 #pragma unroll
                 for (int a1 = 0; a1 < 8; ++a1) { d[a0][a1].x -= mean; d[a0][a1].y -= mean; }
         }
+#if SG_RBIG_B128
+#pragma unroll
+        for (int a0 = 0; a0 < T; a0 += 2)
+#pragma unroll
+            for (int a1 = 0; a1 < 8; ++a1) {                 // rows a0 + T*a1 (even) and the next one in one 16-byte read
+                const v4f w = lds_get2(lds + ((a0 + T * a1) >> 1) * 128 + 2 * lane);
+                d[a0][a1].x *= w.x; d[a0][a1].y *= w.y;
+                d[a0 + 1][a1].x *= w.z; d[a0 + 1][a1].y *= w.w;
+            }
+#else
 #pragma unroll
         for (int a0 = 0; a0 < T; ++a0)
 #pragma unroll
@@ -150,6 +180,7 @@ __global__ __launch_bounds__((64 * WavesFor<T, H>::value), (OccFor<T, H>::value)
                 const float2 w = lds_get(wtab + 64 * (a0 + T * a1));
                 d[a0][a1].x *= w.x; d[a0][a1].y *= w.y;
             }
+#endif
 
         if (SG_RBIG_PRIO) __builtin_amdgcn_s_setprio(0);
         // ---- pass 1: R-point DFT over a = a0 + T*a1 --------------------------------------------------------
@@ -170,11 +201,20 @@ __global__ __launch_bounds__((64 * WavesFor<T, H>::value), (OccFor<T, H>::value)
 #pragma unroll
             for (int r0 = 0; r0 < T; ++r0) d[r0][r1] = v[r0];
         }
+#if SG_RBIG_B128
+#pragma unroll
+        for (int i = 0; i < R - 1; i += 2) {                 // table rows i, i + 1 <-> r = i + 1, i + 2
+            const v4f w = lds_get2(lds + kTw1 + (i >> 1) * 128 + 2 * lane);
+            d[(i + 1) / 8][(i + 1) % 8] = cmul(d[(i + 1) / 8][(i + 1) % 8], make_float2(w.x, w.y));
+            if (i + 2 < R) d[(i + 2) / 8][(i + 2) % 8] = cmul(d[(i + 2) / 8][(i + 2) % 8], make_float2(w.z, w.w));
+        }
+#else
 #pragma unroll
         for (int q = 0; q < T; ++q)
 #pragma unroll
             for (int r1 = 0; r1 < 8; ++r1)
                 if (q + r1 > 0) d[q][r1] = cmul(d[q][r1], lds_get(t1 + 64 * (r1 + 8 * q - 1)));
+#endif
 #pragma unroll
         for (int q = 0; q < T; ++q) {                        // exchange 1, one group of 8 at a time through the slab
 #pragma unroll
@@ -224,12 +264,18 @@ __global__ __launch_bounds__((64 * WavesFor<T, H>::value), (OccFor<T, H>::value)
             for (int sl = 0; sl < 4; ++sl) lds_put(x3w + 64 * sl, SG_Z(R - 4 * i - 4 + sl));
             if (lane == 0) lds_put(buf + 256, i == 0 ? SG_Z(0) : SG_Z(R - 4 * i));   // i = 0: Z[M] := Z[0]
             wave_lds_fence();
+            v4f cs2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) {
                 const int c = 4 * i + cc;
                 const float2 A = SG_Z(c);
                 const float2 B = lds_get(x3b - 64 * cc);
+#if SG_RBIG_B128
+                if (cc % 2 == 0) cs2 = lds_get2(lds + kTw3 + (c >> 1) * 128 + 2 * lane);
+                const float2 cs = cc % 2 == 0 ? make_float2(cs2.x, cs2.y) : make_float2(cs2.z, cs2.w);
+#else
                 const float2 cs = lds_get(t3 + 64 * c);
+#endif
                 const float2 S = make_float2(A.x + B.x, A.y - B.y);
                 const float2 D = make_float2(A.x - B.x, A.y + B.y);
                 const float2 Tt = make_float2(fmaf(cs.y, D.x, -cs.x * D.y), fmaf(cs.x, D.x, cs.y * D.y));
@@ -359,7 +405,7 @@ int launch_tdh(const BigParams& prm, hipStream_t s, int mode, bool band, int n_c
     auto k1 = stft_rbig_kernel<T, DETREND, 1, H>;
     auto k2 = stft_rbig_kernel<T, DETREND, 2, H>;
     auto kern = band ? k2 : mode == SG_MODE_PSD ? k0 : k1;
-    const size_t lds = (static_cast<size_t>(M) + (R - 1 + 7 + R / 2) * 64 + static_cast<size_t>(kWaves) * kSlabElems) * sizeof(float2);
+    const size_t lds = (static_cast<size_t>(M) + ((SG_RBIG_B128 ? R : R - 1) + 7 + R / 2) * 64 + static_cast<size_t>(kWaves) * kSlabElems) * sizeof(float2);
     const int wg_per_cu = static_cast<int>((160 * 1024) / lds) < 1 ? 1 : static_cast<int>((160 * 1024) / lds);
     BigParams p = prm;
     int64_t n_waves = static_cast<int64_t>(n_cu) * wg_per_cu * kWaves;
