@@ -67,7 +67,10 @@ def hop_families(hops: Sequence[int]):
     """Hops that can share ONE transform per n_fft: frame ``i`` at hop ``h`` is frame ``i * h/g`` at hop ``g`` when ``g`` divides
     ``h`` (same samples, same arithmetic: bit-identical rows), so a family ``{h_i}`` is served by the hop-``g`` transform with
     ``g = gcd(h_i)`` and row subsampling -- cfg4's hops 64 / 128 / 256 cost 1 unit of work instead of 1 + 1/2 + 1/4.  A hop
-    joins a family only while the shared transform stays cheaper than separate ones (``1/g <= sum 1/h_i``).
+    joins a family only while the shared transform stays cheaper than separate ones (``1/g <= sum 1/h_i``), and only if the
+    family's gcd keeps the parity of its members: the register kernels of some plans (f64, nfft 256 / 512 / 2048 / 4096) serve
+    even hops only and an odd hop runs on the LDS kernel, whose rows agree with theirs to rounding, not bit for bit -- a family
+    must be one kernel's work for the rows to be IDENTICAL.
     -> ``[(g, [h, ...]), ...]``, deterministic."""
     from math import gcd
     rest = sorted({int(h) for h in hops})
@@ -77,7 +80,7 @@ def hop_families(hops: Sequence[int]):
         g = fam[0]
         for h in list(rest):
             g2 = gcd(g, h)
-            if 1.0 / g2 <= sum(1.0 / m for m in fam) + 1.0 / h + 1e-12:
+            if 1.0 / g2 <= sum(1.0 / m for m in fam) + 1.0 / h + 1e-12 and all(m % 2 == g2 % 2 for m in fam + [h]):
                 fam.append(h)
                 rest.remove(h)
                 g = g2

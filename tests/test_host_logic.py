@@ -257,6 +257,11 @@ def test_hop_families():
     assert hop_families([6, 10, 15]) == [(6, [6]), (10, [10]), (15, [15])]
     for g, fam in hop_families([3, 6, 7, 14, 12, 28]):
         assert all(h % g == 0 for h in fam) and 1.0 / g <= sum(1.0 / h for h in fam) + 1e-12
+        assert all(h % 2 == g % 2 for h in fam)
+    # an odd hop never shares with even ones: on f64 / nfft 256, 512, 2048, 4096 plans it runs on another kernel, and a family's
+    # rows are only IDENTICAL to the separate transforms' when one kernel computes them all (found by the GPU fuzz, seed 1618)
+    assert hop_families([1, 64, 256]) == [(1, [1]), (64, [64, 256])]
+    assert hop_families([3, 9, 27]) == [(3, [3, 9, 27])] and hop_families([1, 2, 4]) == [(1, [1]), (2, [2, 4])]
 
 
 def test_frame_shards_of_one_long_clip():
