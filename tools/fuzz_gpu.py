@@ -120,6 +120,7 @@ for it in range(bcases):
     x = (x * 4000).astype(np.int16) if dt == "i16" else x.astype(np.float32 if dt == "f32" else np.float64)
     fs = float(rng.choice([500.0, 48000.0]))
     ok = True
+    why = []
     try:
         dc = engine.DeviceClips(x)
         for hop in hops:
@@ -130,13 +131,13 @@ for it in range(bcases):
                 fo, to, so = orc.spectrogram(x, **kw)
             tol = 2e-4 if s.dtype == np.float32 else 1e-9
             ref = np.abs(so).max(axis=-2, keepdims=True)
-            ok &= np.array_equal(t, to) and bool(np.all(np.abs(s - so) <= tol * ref + 1e-30))
+            c = np.array_equal(t, to) and bool(np.all(np.abs(s - so) <= tol * ref + 1e-30)); ok &= c; why += [] if c else [f"plain hop {hop}"]
             fp, tp, sp_ = stft_pipelined(x, chunk_bytes=int(rng.choice([1, 1 << 16, 1 << 20, 1 << 26])), **kw)
-            ok &= np.array_equal(tp, to) and bool(np.all(np.abs(sp_ - so) <= tol * ref + 1e-30))
+            c = np.array_equal(tp, to) and bool(np.all(np.abs(sp_ - so) <= tol * ref + 1e-30)); ok &= c; why += [] if c else [f"pipelined hop {hop}"]
             dev = dc.stft(fs=fs, window="hann", nperseg=nper, hop=hop)
             sd = dev.to_host()
             dev.free()
-            ok &= sd.shape == so.shape and bool(np.all(np.abs(sd - so) <= tol * ref + 1e-30))
+            c = sd.shape == so.shape and bool(np.all(np.abs(sd - so) <= tol * ref + 1e-30)); ok &= c; why += [] if c else [f"DeviceClips hop {hop}"]
         for g, fam in hop_families(hops):                      # coarser hops are row subsets of the family's transform
             if len(fam) > 1:
                 dev = dc.stft(fs=fs, window="hann", nperseg=nper, hop=g)
@@ -146,14 +147,14 @@ for it in range(bcases):
                     dev = dc.stft(fs=fs, window="hann", nperseg=nper, hop=h)
                     own = dev.to_host()
                     dev.free()
-                    ok &= bool(np.array_equal(base[..., ::h // g][..., :own.shape[-1]], own))
+                    c = bool(np.array_equal(base[..., ::h // g][..., :own.shape[-1]], own)); ok &= c; why += [] if c else [f"family g={g} h={h} not identical"]
         dc.free()
     except Exception as e:          # noqa: BLE001
         ok = False
         print("EXC", repr(e))
     if not ok:
         bbad += 1
-        print("BATCH FAIL", it, dict(n_clips=n_clips, N=N, dt=str(dt), nperseg=nper, hops=hops, fs=fs))
+        print("BATCH FAIL", it, why, dict(n_clips=n_clips, N=N, dt=str(dt), nperseg=nper, hops=hops, fs=fs))
 print(f"{bcases - bbad}/{bcases} batch-API cases agree with the oracle")
 
 # ---- what PlotEngine does with one GUI-sized signal (A8-A13): mask, store, display image, HMM features, band powers ----
