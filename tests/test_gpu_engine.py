@@ -178,16 +178,18 @@ def test_mel_epilogue_vs_own_oracle():
     dev.free(); dev2.free(); bank.close(); bank2.close()
 
 
+@pytest.mark.parametrize("transport", ["auto", "host", "device"])
 @pytest.mark.parametrize("nperseg,hop,n_ch,fs", [(4096, 1024, 8, 96000.0), (1024, 256, 3, 48000.0), (256, 224, 2, 500.0)])
-def test_streaming_equals_offline(nperseg, hop, n_ch, fs):
-    """cfg5: feeding chunks (4096 samples/channel, plus ragged sizes) yields exactly the offline frames."""
+def test_streaming_equals_offline(nperseg, hop, n_ch, fs, transport):
+    """cfg5: feeding chunks (4096 samples/channel, plus ragged sizes) yields exactly the offline frames -- with the staging rows in
+    HBM (one H2D, one launch, one D2H per chunk) and in pinned host memory (small chunks: the kernel crosses PCIe itself)."""
     import spectro
     from spectro.stream import StreamingSTFT
     rng = np.random.default_rng(nperseg)
     total = nperseg * 6 + 777
     x = (rng.standard_normal((n_ch, total)) * 0.3).astype(np.float32)
-    st = StreamingSTFT(n_ch, fs, nperseg, hop, window="hann")
-    chunks = [4096, 1, 4096, 313, 0, 4096, 5000]
+    st = StreamingSTFT(n_ch, fs, nperseg, hop, window="hann", transport=transport)
+    chunks = [4096, 1, 4096, 313, 0, 4096, 5000, 9000]
     pos, ts, outs = 0, [], []
     while pos < total:
         n = min(chunks[len(ts) % len(chunks)], total - pos)
@@ -204,11 +206,13 @@ def test_streaming_equals_offline(nperseg, hop, n_ch, fs):
     f_o, t_o, s_o = orc.spectrogram(x, fs=fs, nperseg=nperseg, window="hann", noverlap=nperseg - hop)
     np.testing.assert_array_equal(t_all, t_o)
     assert_spec_close(s_all, s_o, time_axis=-1)
+    assert st.transport == ("host" if transport == "auto" else transport)          # these chunk sizes are zero-copy sized
     st.close()
 
 
+@pytest.mark.parametrize("transport", ["host", "device"])
 @pytest.mark.parametrize("nperseg,hop,max_chunk", [(256, 64, 300), (256, 37, 256), (1024, 256, 1000), (100, 100, 64)])
-def test_streaming_many_small_chunks(nperseg, hop, max_chunk):
+def test_streaming_many_small_chunks(nperseg, hop, max_chunk, transport):
     """The staging rows only advance an offset per chunk and move the tail back to the front when they run out of room
     (every ~32 chunks): hundreds of small ragged chunks, even and odd hops, still equal the offline call."""
     import spectro
@@ -216,7 +220,7 @@ def test_streaming_many_small_chunks(nperseg, hop, max_chunk):
     rng = np.random.default_rng(hop)
     total = 60000
     x = (rng.standard_normal((2, total)) * 0.3 + 0.1).astype(np.float32)
-    st = StreamingSTFT(2, 8000.0, nperseg, hop, window="hann", max_chunk=max_chunk)
+    st = StreamingSTFT(2, 8000.0, nperseg, hop, window="hann", max_chunk=max_chunk, transport=transport)
     pos, ts, outs = 0, [], []
     while pos < total:
         n = min(int(rng.integers(0, max_chunk + 1)), total - pos)
