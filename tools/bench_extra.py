@@ -144,5 +144,5 @@ dt = time.perf_counter() - t0
 res["cfg5_streaming"] = {"chunks": n_chunks, "frames": got, "frames_per_s": got / dt,
                          "realtime_factor": (n_chunks * 4096 / 96000.0) / dt,
                          "chunk_latency_ms_median": float(np.median(lat) * 1e3), "chunk_latency_ms_p99": float(np.percentile(lat, 99) * 1e3),
-                         "note": "synchronous feed() incl. H2D of the chunk and D2H of the new frames (PCIe-inclusive)"}
+                         "note": "synchronous feed(), host to host (PCIe-inclusive); chunks this small run with their rows and frames in pinned host memory, the kernel crossing PCIe itself"}
 print(json.dumps(res, indent=1))

@@ -232,7 +232,7 @@ for it in range(scases):
     x = (rng.standard_normal((n_ch, total)) * 0.3 + 0.05).astype(np.float32)
     ok = True
     try:
-        st = StreamingSTFT(n_ch, fs, nper, hop, window="hann", max_chunk=max_chunk)
+        st = StreamingSTFT(n_ch, fs, nper, hop, window="hann", max_chunk=max_chunk, transport=("auto", "device")[it % 2])   # pinned-host rows / HBM rows
         pos, ts, outs = 0, [], []
         while pos < total:
             n = min(int(rng.integers(0, max_chunk + 1)), total - pos)
