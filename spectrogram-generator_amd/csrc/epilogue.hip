@@ -215,7 +215,7 @@ __global__ __launch_bounds__(kThreads) void band_features_kernel(const T* band, 
     }
 }
 
-constexpr int kRowsPerStep = 8;
+constexpr int kRowsPerStep = 16;        // rows a wave has in flight per 64-bin step (8: 86-90 us, 16: 73 us, 32: 78-80 us per cfg2 spectrum, balanced runs)
 struct Bands { int n; int k_begin; int k_end; int lo[16]; int hi[16]; };     // [lo, hi) each; [k_begin, k_end) their hull
 
 // A13: every band total from one read of the rows.  A wave takes kRowsPerStep rows at a time, 64 bins per step:
@@ -232,9 +232,13 @@ __global__ __launch_bounds__(kThreads) void band_totals_kernel(const T* spec, in
 #pragma unroll
     for (int ib = 0; ib < 16; ++ib) acc[ib] = 0.0;
     const int c_begin = b.k_begin & ~63;
-    for (int64_t f0 = wave * R; f0 < n_frames; f0 += n_waves * R) {
+    // every wave owns one contiguous, balanced run of rows (round 3): with R-row groups dealt round-robin over a grid larger than the chip
+    // holds, cfg2's 14 976 groups were 1.8 per wave -- some waves did two, some one, and the workgroups of the second round waited for
+    // the first: 105 us; one resident round of equal runs, 16 rows per step: 73 us (profiles/r03_band_totals_runs.txt)
+    const int64_t r_end = n_frames * (wave + 1) / n_waves;
+    for (int64_t f0 = n_frames * wave / n_waves; f0 < r_end; f0 += R) {
         const T* const rows = spec + f0 * n_bins;
-        const int nr = n_frames - f0 < R ? static_cast<int>(n_frames - f0) : R;
+        const int nr = r_end - f0 < R ? static_cast<int>(r_end - f0) : R;
         T seg[16];                                 // a lane's share of R rows (few terms); row groups add up in double
 #pragma unroll
         for (int ib = 0; ib < 16; ++ib) seg[ib] = T(0);
@@ -649,7 +653,11 @@ int sg_band_totals(const void* spec_dev, int dtype, int64_t n_frames, int n_bins
     std::lock_guard<std::recursive_mutex> seq(launch_sequence_mutex(s));
     double* const parts = static_cast<double*>(reduction_scratch(s));
     if (!parts) { set_error("band_totals: no scratch memory"); return SG_ERR_HIP; }
-    const unsigned g = grid_for((n_frames + kRowsPerStep - 1) / kRowsPerStep * 64, kMaxParts);
+    // one round of resident workgroups (4 per CU at this kernel's register use), never more waves than row groups
+    int cap = device_cu_count() * 4;
+    if (const char* e = getenv("SPECTRO_TOTALS_WG_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 8) cap = device_cu_count() * v; }   // tuning aid
+    if (cap > kMaxParts) cap = kMaxParts;
+    const unsigned g = grid_for((n_frames + kRowsPerStep - 1) / kRowsPerStep * 64, cap);
     if (dtype == SG_F32)
         hipLaunchKernelGGL(band_totals_kernel<float>, dim3(g), dim3(kThreads), 0, s, static_cast<const float*>(spec_dev), n_frames,
                            n_bins, b, parts);

@@ -127,10 +127,11 @@ __global__ __launch_bounds__((64 * WavesFor<T, H>::value), (OccFor<T, H>::value)
     int64_t g = p.total_frames * lw / p.n_waves;
     const int64_t g_end = p.total_frames * (lw + 1) / p.n_waves;
 
-    const float2* const wtab = lds + lane;                   // + 64*a
-    const float2* const t1 = lds + kTw1 + lane;              // + 64*(r-1)
-    const float2* const t2 = lds + kTw2 + lane;              // + 64*(s-1)
-    const float2* const t3 = lds + kTw3 + lane;              // + 64*c
+    // (SG_RBIG_B128: the window, t1 and t3 tables are read in pairs from their paired layout, see the table fill above)
+    [[maybe_unused]] const float2* const wtab = lds + lane;                   // + 64*a
+    [[maybe_unused]] const float2* const t1 = lds + kTw1 + lane;              // + 64*(r-1)
+    const float2* const t2 = lds + kTw2 + lane;                               // + 64*(s-1)
+    [[maybe_unused]] const float2* const t3 = lds + kTw3 + lane;              // + 64*c
     const int j0 = lane & 7, hi = lane >> 3;
     float2* const x1w = buf + hi * kS1 + j0;                 // + 8*r1            (group q)
     float2* const x1r = buf + lane;                          // + b*kS1
