@@ -117,6 +117,56 @@ __global__ __launch_bounds__(256) void rows_k(const float* __restrict__ x, float
     }
 }
 
+// Round 3: the same rows (SHAPE 0), but a wave requests row f + DEPTH while it stores row f, with unconditional (clamped) loads so that
+// the compiler's s_waitcnt is exact: vmcnt counts loads and stores in one in-order queue, so with DEPTH = 1 the wait for the next row's
+// samples also waits for the stores of the row before (one row of stores in flight per wave); DEPTH = 2 / 3 leave two / three rows of stores
+// in flight.  Does the memory system take more from the SAME 3 072 streams if each has more in flight?
+template <int DEPTH>
+__global__ __launch_bounds__(256) void rows_deep_k(const float* __restrict__ x, float* __restrict__ out, long n_rows, int n_waves) {
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= n_waves) return;
+    const long g0 = n_rows * w / n_waves, g1 = n_rows * (w + 1) / n_waves;
+    if (g0 >= g1) return;
+    float2 v[DEPTH], u[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+        const long r = g0 + d < g1 ? g0 + d : g1 - 1;
+        v[d] = *reinterpret_cast<const float2*>(x + r * 256 + 2 * lane);
+        u[d] = *reinterpret_cast<const float2*>(x + r * 256 + 128 + 2 * lane);
+    }
+    for (long f = g0; f < g1; ++f) {
+        const long r = f + DEPTH < g1 ? f + DEPTH : g1 - 1;
+        const float2 vn = *reinterpret_cast<const float2*>(x + r * 256 + 2 * lane);
+        const float2 un = *reinterpret_cast<const float2*>(x + r * 256 + 128 + 2 * lane);
+        const float s = v[0].x + v[0].y + u[0].x + u[0].y;
+        float* row = out + f * 513;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { row[lane + 64 * m] = s; row[512 - lane - 64 * m] = s; }
+        row[256] = s;
+#pragma unroll
+        for (int d = 0; d + 1 < DEPTH; ++d) { v[d] = v[d + 1]; u[d] = u[d + 1]; }
+        v[DEPTH - 1] = vn; u[DEPTH - 1] = un;
+    }
+}
+
+template <int DEPTH>
+void rows_deep(const float* x, float* out, int occ) {
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const long n_rows = 119808L * 8;
+    const int n_waves = 256 * 4 * occ, grid = n_waves / 4;
+    hipLaunchKernelGGL((rows_deep_k<DEPTH>), dim3(grid), dim3(256), 0, 0, x, out, n_rows, n_waves);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    const int reps = 4;
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((rows_deep_k<DEPTH>), dim3(grid), dim3(256), 0, 0, x, out, n_rows, n_waves);
+    CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    printf("stft rows, %d row(s) requested ahead   occ %d waves/SIMD: %.2f TB/s  (%.1f us per 119808 rows)\n", DEPTH, occ,
+           (double)n_rows * 3076 * reps / (ms * 1e-3) / 1e12, ms * 1e3 / reps / 8);
+    fflush(stdout);
+}
+
 static float* g_sink;
 static double g_best;
 
@@ -187,6 +237,14 @@ int main(int argc, char** argv) {
         }
         const double per = !strcmp(argv[2], "rows") ? 119808.0 * 8 * 3076 : !strcmp(argv[2], "mix") ? 3 * B : B;
         printf("sustain %s: %.2f TB/s over %.1f s\n", argv[2], per * n / el / 1e12, el);
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "deep")) {          // ./hbm_peaks.bin deep: rows requested 1 / 2 / 3 ahead of the stores
+        float *a1, *b1;
+        CHECK(hipMalloc(&a1, (size_t)2 << 30)); CHECK(hipMalloc(&b1, (size_t)4 << 30));
+        CHECK(hipMemset(a1, 0, (size_t)2 << 30));
+        for (int rep = 0; rep < 2; ++rep)
+            for (int occ : {2, 3, 4}) { rows_deep<1>(a1, b1, occ); rows_deep<2>(a1, b1, occ); rows_deep<3>(a1, b1, occ); }
         return 0;
     }
     const bool rows_only = argc > 1 && !strcmp(argv[1], "rows");     // ./hbm_peaks.bin rows: only the STFT row-pattern models
