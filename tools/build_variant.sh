@@ -1,6 +1,6 @@
 #!/bin/bash
 # Build a variant of libspectro.so into spectrogram-generator_amd/lib_<name>/ for tools/ab.sh:
-#   tools/build_variant.sh <name> <file.hip> "<extra hipcc flags>"      (other objects are taken from lib/)
+#   tools/build_variant.sh <name> <file.hip> "<extra hipcc flags>"      (other objects are taken from lib/; a copy named <file>_tmp.hip stands in for <file>.hip)
 set -e
 name=$1; src=$2; defs=$3
 R=$(cd "$(dirname "$0")/.." && pwd)
