@@ -322,6 +322,29 @@ def test_sharded_sweep_single_rank_on_device():
         assert np.array_equal(v, res[k]), k
 
 
+def test_sharded_sweep_products_left_on_the_device():
+    """What the RCCL gather sends: the reduced products stay in HBM as torch tensors over the library's blocks (zero-copy through
+    __cuda_array_interface__) until the gather has moved them.  One rank: same numbers, bit for bit, as the host-array path -- and
+    torch is imported AFTER the engine here, which needs the two to share one HIP runtime."""
+    from spectro import sweep
+    rng = np.random.default_rng(23)
+    clips = (rng.standard_normal((3, 20000)) * 0.2).astype(np.float32)
+    args = (clips, 8000.0, [256, 1024, 2048], [64, 128, 256])
+    host = sweep.sharded_sweep(*args, fmin=100.0, fmax=3000.0)
+    for kw in (dict(), dict(share_hops=False)):
+        dev = sweep.sharded_sweep(*args, fmin=100.0, fmax=3000.0, device_products=True, **kw)
+        assert dev.keys() == host.keys() and len(dev) == 3 * 9
+        for k, v in dev.items():
+            assert isinstance(v, np.ndarray) and np.array_equal(v, host[k]), k
+    # a clip too short for the largest n_fft (nperseg clamps, one frame) and an empty band, still on the device
+    short = (rng.standard_normal((2, 700)) * 0.2).astype(np.float32)
+    a = sweep.sharded_sweep(short, 8000.0, [256, 1024], [64], fmin=100.0, fmax=3000.0)
+    b = sweep.sharded_sweep(short, 8000.0, [256, 1024], [64], fmin=100.0, fmax=3000.0, device_products=True)
+    assert all(np.array_equal(a[k], b[k]) for k in a) and {v.shape for k, v in b.items() if k[1] == 1024} == {(1,)}
+    e = sweep.sharded_sweep(short, 8000.0, [256], [64], fmin=3999.0, fmax=3999.5, device_products=True)
+    assert all(np.all(v == np.log10(np.float32(1e-20))) for v in e.values())
+
+
 def test_device_clips_products_vs_oracle():
     """DeviceClips: clips uploaded once; band features (whole batch and a clip range), log display through the fused kernel
     (nperseg 1024) and through the composed path (nperseg 512), int16 clips."""
