@@ -68,7 +68,10 @@ def global_max(local_max):
     d = _dist()
     world, _ = world_info()
     if world > 1:
-        d.all_reduce(local_max, op=d.ReduceOp.MAX)
+        t, staged = _comm_tensor(local_max)                  # RCCL reduces device memory only: a host tensor goes through this rank's GPU
+        d.all_reduce(t, op=d.ReduceOp.MAX)
+        if staged:
+            local_max.copy_(t.cpu())
     return local_max
 
 

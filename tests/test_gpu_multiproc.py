@@ -46,6 +46,23 @@ SWEEP_SCRIPT = textwrap.dedent('''
     whole = engine.stft(clips, fs=8000.0, nperseg=1024, window="hann", noverlap=768)
     assert gmax == float(whole.minmax(0, whole.n_bins - 1)[1]), "global_max over the shards != maximum of the batch"
     whole.free()
+    # the branch RCCL takes -- host tensors staged through this rank's GPU -- with gloo doing the reduction (it reduces device tensors too)
+    real_backend, sd._backend = sd._backend, (lambda: "nccl")
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    assert float(sd.global_max(t)[0]) == 2.0 and not t.is_cuda
+    assert sd.all_agree(True) and not sd.all_agree(rank == 0)
+    # ... and the gather's staged peer sends (device tensors out, host tensors back on the root), if this gloo build moves device memory
+    part = torch.full((2 + rank, 3), float(rank), dtype=torch.float32)
+    try:
+        got = sd.gather_to_root([part], dst=0, shapes=[[(2, 3)], [(3, 3)]])
+        if rank == 0:
+            assert [tuple(g[0].shape) for g in got] == [(2, 3), (3, 3)] and float(got[1][0].sum()) == 9.0 and not got[1][0].is_cuda
+        staged_gather = "ok"
+    except RuntimeError as e:                                # gloo without device send / recv: the branch stays untested here
+        staged_gather = "unsupported by gloo: " + str(e)[:80]
+    sd._backend = real_backend
+    dist.barrier()
+    os.write(1, ("rank %d staged gather: %s" % (rank, staged_gather) + chr(10)).encode())
     # the sweep: batched deal with shared hops (default), batched without sharing, per-item deal
     res = {name: sweep.sharded_sweep(clips, 8000.0, n_ffts, hops, fmin=100.0, fmax=3000.0, **kw)
            for name, kw in (("shared", {}), ("plain", dict(share_hops=False)), ("items", dict(batched=False)))}
@@ -73,6 +90,7 @@ def test_two_ranks_on_one_gpu_sweep_equals_single_rank(tmp_path):
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+    assert r.stdout.count("staged gather: ok") == 2, r.stdout[-1500:]     # the device-tensor branch of gather_to_root ran (this image's gloo moves device memory)
     # the single-rank result, computed here through the same entry point
     sys.path.insert(0, PKG)
     from spectro import sweep
