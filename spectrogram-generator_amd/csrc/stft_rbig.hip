@@ -452,9 +452,11 @@ int launch_t(const sg_plan& p, const StftArgs& a) {
         else if (p.hop == 64 || p.hop == 32 || p.hop == 16) { h = 1; prm.sub = 128 / p.hop; }
     }
     const bool band = a.band_mode != 0;                    // run_stft has checked: psd plan, 0 <= k_lo <= k_hi < n_bins
-    // T = 4 slides at 2 waves/SIMD (64 more VGPRs): -13...16 % with the rows written, +4 % for the band sums alone (no stores to
-    // hide behind; 1.34 against 1.29 ms per 64-clip batch at hop 64) -- the band form keeps reloading
-    if (T == 4 && band) { h = 0; prm.sub = 1; }
+    // T = 4 slides at 2 waves/SIMD (64 more VGPRs): -13...16 % with the rows written.  For the band sums alone (no stores to hide
+    // behind) sliding lost by 4 % in round 2 (1.34 against 1.29 ms per 64-clip batch at hop 64); since the table reads went to
+    // ds_read_b128 and the pass-2 twiddles to registers it wins: 1.185 / 0.611 / 0.320 against 1.277 / 0.651 / 0.335 ms at hops
+    // 64 / 128 / 256 (profiles/r03_rbig_band_slide.txt).  SPECTRO_RBIG_BAND_RELOAD=1 restores the reloading form for an A/B.
+    if (T == 4 && band && getenv("SPECTRO_RBIG_BAND_RELOAD")) { h = 0; prm.sub = 1; }
     return p.detrend == SG_DETREND_CONSTANT ? launch_td<T, true>(prm, a.stream, p.mode, band, p.n_cu, h)
                                             : launch_td<T, false>(prm, a.stream, p.mode, band, p.n_cu, h);
 }
