@@ -67,7 +67,9 @@ FP32_PEAK_TFLOPS = 157.3
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="GPUs (= ranks) of this node; default: WORLD_SIZE under a launcher, else 1.  Given explicitly, a launcher whose "
+                         "WORLD_SIZE differs is refused")
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--clips", type=int, default=CLIPS_PER_GPU, help="clips per GPU (default: BASELINE cfg2 = 64)")
@@ -87,6 +89,8 @@ def parse():
     ap.add_argument("--master-port", type=int, default=0, help="--gpus N > 1 without a launcher: rendezvous port of the ranks this script starts (0: pick a free one)")
     ap.add_argument("--dry-run-spawn", action="store_true", help="print the launcher command --gpus N would start, as JSON, and exit (no GPU needed)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the (untimed-region) gather measurement")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the untimed `secondary` legs (cfg3 fused mel, cfg4 sweep, cfg5 streaming, the >= 4 GB batch; about 3 s)")
     ap.add_argument("--gather-full", action="store_true", help="N > 1: also time the gather of the full spectra to rank 0")
     return ap.parse_args()
 
@@ -199,6 +203,8 @@ def spawn_ranks(args, argv):
 def main():
     args = parse()
     in_launcher = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if args.gpus is None:                                  # `torchrun --nproc-per-node=8 bench.py`: the launcher's world is the answer
+        args.gpus = int(os.environ["WORLD_SIZE"]) if in_launcher else 1
     if args.dry_run_spawn or (args.gpus > 1 and not in_launcher):
         raise SystemExit(spawn_ranks(args, [a for a in sys.argv[1:] if a != "--dry-run-spawn"]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -220,7 +226,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # SPECTRO_BENCH_FORCE_DIST=1 under a launcher with WORLD_SIZE=1: the process group, the barrier, the all_reduce(MAX) of the
+    # times and the gather run through RCCL with one rank -- the N > 1 code path on a one-GPU box (tests/test_gpu_multiproc.py)
+    use_dist = world > 1 or (in_launcher and os.environ.get("SPECTRO_BENCH_FORCE_DIST") == "1")
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if same_gpu:
             dist.init_process_group("gloo")
@@ -273,7 +282,7 @@ def main():
     _e1.record()
     torch.cuda.synchronize(dev)
     _e0.elapsed_time(_e1)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -285,14 +294,14 @@ def main():
     while not ev1.query():                            # poll instead of sleeping in the driver: the blocking synchronize below wakes
         pass                                          # up tens of us late, which a 20-step region would book as kernel time
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         torch.cuda.synchronize(dev)                   # (RCCL's barrier is device work; with one rank there is nothing more to wait for)
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)                    # HIP events on the launch stream
 
     t = torch.tensor([elapsed, dev_ms], device="cpu" if same_gpu else dev, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed_max, dev_ms_max = float(t[0]), float(t[1])
 
@@ -338,8 +347,16 @@ def main():
         except Exception as e:
             print(f"[bench] reference-mode leg failed: {e}", file=sys.stderr)
 
+    # BASELINE's other configs and SURVEY H7's >= 4 GB batch, untimed legs after the headline region (never part of `value`)
+    secondary = None
+    if rank == 0 and world == 1 and n_clips == CLIPS_PER_GPU and not args.no_secondary:
+        try:
+            secondary = time_secondary(_capi, get_window, xs, dev, stream)
+        except Exception as e:
+            print(f"[bench] secondary legs failed: {type(e).__name__}: {e}", file=sys.stderr)
+
     gather = None
-    if world > 1 and not args.no_gather:
+    if use_dist and not args.no_gather:
         gather = time_gather(args, plan, xs[0], outs[0], n_clips, n_frames, dev, same_gpu, world, rank, stream)
 
     if rank == 0:
@@ -405,6 +422,8 @@ def main():
             res["limiter"] = limiter
         if ref_mode:
             res["reference_mode"] = ref_mode
+        if secondary:
+            res["secondary"] = secondary
         if gather:
             res["gather"] = gather
         if world == 1 and not args.no_cpu_baseline:
@@ -413,7 +432,7 @@ def main():
                      * np.float32(0.1))
             res["cpu_baseline"] = time_cpu_baseline(clips, FS, NPERSEG, HOP, budget_s=args.cpu_budget)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
@@ -474,6 +493,120 @@ def time_limiter_leg(_capi, plan, xs, outs, n_clips, n_frames, dev, stream, secs
     else:
         out["reading"] = ("clock-bound share %.2f: with the clock %.0f %% higher on zero data the launch is %.1f %% shorter -- the power cap "
                           "(through the clock it allows) sets a large part of its time" % (share, (cz / cr - 1) * 100, (1 - uz / ur) * 100))
+    return out
+
+
+def time_secondary(_capi, get_window, xs, dev, stream):
+    """BASELINE configs 3, 4 and 5 and SURVEY H7's >= 4 GB batch as UNTIMED legs after the headline region (about 3 s in all; the
+    headline's `value` / `ms_per_step` / `roofline` never see them).  Same clips as the headline leg (64 x 480 000 f32, the four
+    rotating input sets), HIP events on the launch stream, outputs rotating through a pool larger than the Infinity Cache.
+    tools/bench_extra.py is the long form of the same measurements (profiles/r0N_extra_*.json)."""
+    import numpy as np
+    import torch
+    from spectro.mel import MelBank
+    from spectro.stream import StreamingSTFT
+    n_clips = xs[0].shape[0]
+    out = {"note": "untimed legs after the headline region; inputs resident in HBM (cfg5: host to host), rotating buffers, HIP events"}
+
+    def timed(fn, min_iters, settle_s=0.08, budget_s=0.12):
+        """us per call: `settle_s` of back-to-back calls, then at least `min_iters` calls between two events"""
+        k, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < settle_s:
+            for _ in range(4):
+                fn(k)
+                k += 1
+            torch.cuda.synchronize(dev)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n, t0 = 0, time.perf_counter()
+        ev0.record()
+        while n < min_iters or time.perf_counter() - t0 < budget_s:
+            for _ in range(4):
+                fn(k)
+                k += 1
+                n += 1
+            if n >= 4096:
+                break
+        ev1.record()
+        torch.cuda.synchronize(dev)
+        return ev0.elapsed_time(ev1) * 1e3 / n
+
+    # ---- cfg3: the same batch + 80-band mel, fused (the linear spectrum never reaches HBM): hop*4 + 80*4 = 1344 B per frame
+    plan = _capi.Plan(NPERSEG, NPERSEG, HOP, get_window("hann", NPERSEG), _capi.DETREND["constant"], FS, _capi.SCALING["density"], _capi.MODE["psd"], _capi.F32)
+    nfr = plan.n_frames(N_SAMPLES)
+    bank = MelBank(NPERSEG, FS, 80, 0.0, FS / 2)
+    mels = [torch.empty((n_clips, nfr, 80), device=dev, dtype=torch.float32) for _ in range(2)]
+    us = timed(lambda i: bank.stft_mel_ptr(plan, xs[i % len(xs)].data_ptr(), N_SAMPLES, N_SAMPLES, n_clips, mels[i % 2].data_ptr(), nfr * 80, True, stream=stream), 64)
+    out["cfg3_fused_mel"] = {"us": us, "frames": n_clips * nfr, "frames_per_s": n_clips * nfr / us * 1e6, "bytes_per_frame": HOP * 4 + 80 * 4,
+                             "achieved_GBs": n_clips * nfr * (HOP * 4 + 80 * 4) / us / 1e3, "n_mels": 80, "log": True,
+                             "kernel": "stft1024_r8x3_kernel OUT_MEL (band-sparse epilogue)"}
+    bank.close()
+    plan.close()
+    del mels
+
+    # ---- cfg4: n_fft x hop sweep, this GPU's 64-clip share of the 256-clip job: spectra, and the fused band power the sweep gathers
+    n_ffts, hops = (256, 512, 1024, 2048, 4096), (64, 128, 256)
+    biggest = max(n_clips * ((N_SAMPLES - n) // h + 1) * (n // 2 + 1) for n in n_ffts for h in hops)
+    pool = torch.empty(2 * biggest, device=dev, dtype=torch.float32)           # two output sets of the largest shape (2 x 3.9 GB)
+    bp = torch.empty(n_clips * ((N_SAMPLES - 256) // 64 + 1), device=dev, dtype=torch.float32)
+    per_pair, total, shared, band_total, band_shared = [], 0.0, 0.0, 0.0, 0.0
+    for n in n_ffts:
+        for h in hops:
+            p = _capi.Plan(n, n, h, get_window("hann", n), _capi.DETREND["constant"], FS, _capi.SCALING["density"], _capi.MODE["psd"], _capi.F32)
+            nf, nb = p.n_frames(N_SAMPLES), n // 2 + 1
+            sz = n_clips * nf * nb
+            n_out = max(2, min(8, int(2 * biggest // sz)))                   # small shapes rotate through more sets: past the cache
+            est = 1e-9 * n_clips * nf * (n / 256) * 1.2                       # s per launch, roughly
+            iters = max(8, min(256, int(0.03 / est)))
+            us = timed(lambda i: p.stft(xs[i % len(xs)].data_ptr(), N_SAMPLES, N_SAMPLES, n_clips, pool[(i % n_out) * sz:].data_ptr(), nf * nb, stream=stream),
+                       iters, settle_s=0.03, budget_s=0.0)
+            us_b = timed(lambda i: p.band_power(xs[i % len(xs)].data_ptr(), N_SAMPLES, N_SAMPLES, n_clips, 1, n // 4, bp.data_ptr(), nf, stream=stream),
+                         iters, settle_s=0.03, budget_s=0.0)
+            bpf = h * 4 + nb * 4
+            per_pair.append({"n_fft": n, "hop": h, "kernel": p.kernel, "frames": n_clips * nf, "us": us, "frames_per_s": n_clips * nf / us * 1e6,
+                             "bytes_per_frame": bpf, "frac_of_hbm_peak": n_clips * nf * bpf / us / 1e3 / HBM_PEAK_GBS, "band_power_us": us_b})
+            total += us
+            band_total += us_b
+            if h == min(hops):
+                shared += us
+                band_shared += us_b
+            p.close()
+    out["cfg4_sweep_64clips"] = {"total_ms": total / 1e3, "shared_hops_ms": shared / 1e3, "band_power_ms": band_total / 1e3,
+                                 "band_power_shared_hops_ms": band_shared / 1e3, "per_pair": per_pair,
+                                 "note": "15 (n_fft, hop) pairs on 64 clips x 480 000 samples; shared_hops: hops 128 / 256 taken as row subsets of the "
+                                         "hop-64 transform (spectro.sweep.hop_families); band_power: the fused reduced product sharded_sweep gathers"}
+    del pool, bp
+
+    # ---- SURVEY H7: one launch over >= 4 GB (768 clips: 1.47 GB in, 2.95 GB out), the headline plan
+    big_clips = 768
+    plan = _capi.Plan(NPERSEG, NPERSEG, HOP, get_window("hann", NPERSEG), _capi.DETREND["constant"], FS, _capi.SCALING["density"], _capi.MODE["psd"], _capi.F32)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(99)
+    xb = torch.randn((big_clips, N_SAMPLES), device=dev, dtype=torch.float32, generator=gen) * 0.1
+    ob = torch.empty((big_clips, nfr, N_BINS), device=dev, dtype=torch.float32)
+    us = timed(lambda i: plan.stft(xb.data_ptr(), N_SAMPLES, N_SAMPLES, big_clips, ob.data_ptr(), nfr * N_BINS, stream=stream), 12, settle_s=0.1, budget_s=0.0)
+    fr = big_clips * nfr
+    out["large_batch"] = {"clips": big_clips, "GB": (xb.numel() + ob.numel()) * 4 / 1e9, "frames": fr, "us": us, "frames_per_s": fr / us * 1e6,
+                          "frac": fr * BYTES_PER_FRAME / us / 1e3 / HBM_PEAK_GBS, "bytes_per_frame": BYTES_PER_FRAME}
+    plan.close()
+    del xb, ob
+
+    # ---- cfg5: streaming 8 ch x 96 kHz, n_fft 4096 hop 1024, 4096-sample chunks, synchronous feed() host to host (PCIe inclusive)
+    st = StreamingSTFT(8, 96000.0, 4096, 1024, window="hann")
+    chunk = (np.random.default_rng(5).standard_normal((8, 4096)) * 0.1).astype(np.float32)
+    for _ in range(8):
+        st.feed(chunk)
+    lat, frames, t0 = [], 0, time.perf_counter()
+    for _ in range(300):
+        c0 = time.perf_counter()
+        _, sx = st.feed(chunk)
+        lat.append(time.perf_counter() - c0)
+        frames += sx.shape[-1] * 8
+    dt = time.perf_counter() - t0
+    st.close()
+    out["cfg5_streaming"] = {"chunks": 300, "chunk_ms_p50": float(np.median(lat) * 1e3), "chunk_ms_p99": float(np.percentile(lat, 99) * 1e3),
+                             "frames_per_s": frames / dt, "realtime_factor": (300 * 4096 / 96000.0) / dt,
+                             "note": "8 ch x 96 kHz, n_fft 4096 hop 1024, numpy chunk in -> numpy frames out per feed()"}
+    torch.cuda.empty_cache()
     return out
 
 
@@ -563,11 +696,11 @@ def time_gather(args, plan, x, out, n_clips, n_frames, dev, same_gpu, world, ran
     if args.gather_full:
         sendf = out[:n_clips].cpu() if same_gpu else out[:n_clips]
         shapes = [None] * world
-        dist.all_gather_object(shapes, [tuple(sendf.shape)])
-        t_best, got = best_of(lambda: sdist.gather_to_root([sendf], dst=0, shapes=shapes))
+        dist.all_gather_object(shapes, [(tuple(sendf.shape), "float32")])
+        t_best, got = best_of(lambda: sdist.gather_to_root([sendf], dst=0, shapes=shapes, checked=True))
         if rank == 0:
-            nbytes = sum(int(torch.tensor(s[0]).prod()) * 4 for r, s in enumerate(shapes) if r != 0)
-            ok = all(tuple(g[0].shape) == tuple(shapes[r][0]) for r, g in enumerate(got))
+            nbytes = sum(int(torch.tensor(s[0][0]).prod()) * 4 for r, s in enumerate(shapes) if r != 0)
+            ok = all(tuple(g[0].shape) == tuple(shapes[r][0][0]) for r, g in enumerate(got))
             res["full_spectra"] = {"gather_ms": t_best * 1e3, "bytes_to_root": nbytes, "gather_GBps": nbytes / t_best / 1e9 if t_best > 0 else None,
                                    "collective": "batched isend / irecv to rank 0", "shapes_ok": ok}
     if rank == 0:

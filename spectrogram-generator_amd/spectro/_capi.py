@@ -93,26 +93,90 @@ class SpectroError(RuntimeError):
     pass
 
 
+def _elf_dynamic(path):
+    """(DT_SONAME, [DT_NEEDED ...]) of a 64-bit little-endian ELF file, read from its section headers (no readelf needed)."""
+    import struct
+    with open(path, "rb") as fh:
+        ident = fh.read(64)
+        if ident[:4] != b"\x7fELF" or ident[4] != 2 or ident[5] != 1:
+            raise OSError(f"{path}: not a 64-bit little-endian ELF file")
+        e_shoff, = struct.unpack_from("<Q", ident, 0x28)
+        e_shentsize, e_shnum = struct.unpack_from("<HH", ident, 0x3A)
+        fh.seek(e_shoff)
+        heads = [struct.unpack_from("<IIQQQQIIQQ", fh.read(e_shentsize)) for _ in range(e_shnum)]
+        dyn = next((h for h in heads if h[1] == 6), None)    # SHT_DYNAMIC; sh_link = its string table
+        if dyn is None:
+            return None, []
+        strtab = heads[dyn[6]]
+        fh.seek(strtab[4]); names = fh.read(strtab[5])
+        fh.seek(dyn[4]); raw = fh.read(dyn[5])
+
+    def name(off):
+        return names[off:names.index(b"\0", off)].decode()
+    soname, needed = None, []
+    for i in range(0, len(raw) - 15, 16):
+        tag, val = struct.unpack_from("<qQ", raw, i)
+        if tag == 0:
+            break
+        if tag == 1:
+            needed.append(name(val))
+        elif tag == 14:
+            soname = name(val)
+    return soname, needed
+
+
+hip_runtime = {"choice": None, "path": None, "why": None}   # which HIP runtime lib() arranged for, and why (read by the tests / for bug reports)
+
+
 def _share_torchs_hip_runtime():
     """PyTorch-ROCm wheels bundle their own ``libamdhip64.so`` and ask for it by that unversioned name, so a process that has
     loaded libspectro.so first (against the system's ``libamdhip64.so.7``) gets a SECOND HIP / HSA runtime when torch is imported
     later -- and the second one finds no GPU ("No HIP GPUs are available"), which would break ``spectro.dist`` / ``spectro.sweep``
     for a caller who touched the engine before importing torch.  Loaded in this order instead -- torch's runtime first, by path --
-    the dynamic linker gives libspectro.so the same copy (its soname is the one libspectro.so needs), and torch finds it loaded.
-    ``SPECTRO_HIP_RUNTIME=system`` keeps the system runtime (processes that never import torch need nothing else)."""
+    the dynamic linker gives libspectro.so the same copy, and torch finds it loaded.  That only holds when the SONAME of torch's
+    copy is the very name libspectro.so asks for (its DT_NEEDED entry): both are read from the ELF files, and a torch built for
+    another ROCm major is left alone -- libspectro.so then runs on the system runtime it was built against, with a warning that a
+    torch imported later in this process will not see the GPU.
+    ``SPECTRO_HIP_RUNTIME``: ``auto`` (default: as above), ``system`` (never preload; processes that never import torch need
+    nothing else), ``torch`` (preload or raise).  ``hip_runtime`` records what was done."""
     import sys
-    if "torch" in sys.modules or os.environ.get("SPECTRO_HIP_RUNTIME", "auto") == "system":
-        return
+    import warnings
+    want = os.environ.get("SPECTRO_HIP_RUNTIME", "auto")
+    if want not in ("auto", "system", "torch"):
+        raise ValueError(f"SPECTRO_HIP_RUNTIME={want!r}: expected auto, system or torch")
+
+    def settle(choice, path, why):
+        hip_runtime.update(choice=choice, path=path, why=why)
+        if os.environ.get("SPECTRO_VERBOSE"):
+            print(f"[spectro] HIP runtime: {choice}" + (f" ({path})" if path else "") + f" -- {why}", file=sys.stderr)
+    if "torch" in sys.modules:
+        return settle("loaded", None, "torch was imported first: its runtime is already mapped")
+    if want == "system":
+        return settle("system", None, "SPECTRO_HIP_RUNTIME=system")
     try:
         import importlib.util
         spec = importlib.util.find_spec("torch")           # locates the package without importing it
-        if spec is None or not spec.submodule_search_locations:
-            return
-        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
-        if os.path.exists(path):
-            C.CDLL(path, mode=C.RTLD_GLOBAL)
-    except OSError:
-        pass                                               # torch's copy does not load here: the system runtime it is
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so") if spec and spec.submodule_search_locations else None
+        if not path or not os.path.exists(path):
+            if want == "torch":
+                raise ImportError("SPECTRO_HIP_RUNTIME=torch: no torch/lib/libamdhip64.so in this environment")
+            return settle("system", None, "no torch (or no bundled HIP runtime) here")
+        soname, _ = _elf_dynamic(path)
+        _, needed = _elf_dynamic(LIB_PATH)
+        mine = [n for n in needed if n.startswith("libamdhip64.so")]
+        if soname not in mine:
+            msg = (f"torch bundles a HIP runtime with SONAME {soname!r}, libspectro.so needs {mine or needed}: they cannot be shared; "
+                   "libspectro.so runs on the system runtime and a torch imported later in this process will not see the GPU")
+            if want == "torch":
+                raise ImportError("SPECTRO_HIP_RUNTIME=torch: " + msg)
+            warnings.warn(msg, RuntimeWarning, stacklevel=3)
+            return settle("system", None, f"SONAME {soname!r} is not what libspectro.so needs ({mine})")
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+        return settle("torch", path, f"SONAME {soname} == libspectro.so's DT_NEEDED")
+    except OSError as e:                                     # torch's copy does not load or parse here: the system runtime it is
+        if want == "torch":
+            raise ImportError(f"SPECTRO_HIP_RUNTIME=torch: {e}") from e
+        return settle("system", None, f"torch's copy is unusable here ({e})")
 
 
 def lib():

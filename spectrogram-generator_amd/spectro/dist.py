@@ -14,6 +14,7 @@ root's 7 inbound links and gains nothing from a ring, so ``gather_to_root`` post
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Sequence
 
 import numpy as np
@@ -63,11 +64,25 @@ def world_info():
     return 1, 0
 
 
+# A world of ONE normally skips every collective.  With this set (or SPECTRO_DIST_FORCE_COLLECTIVES=1) and a process group
+# initialised, the collectives run anyway -- RCCL executes them as one-rank collectives -- so that the code RCCL runs at N > 1
+# (communicator set-up, host tensors staged through the GPU, all_reduce / all_gather on device memory) can be executed on a
+# one-GPU box (tests/test_gpu_multiproc.py).
+FORCE_COLLECTIVES = os.environ.get("SPECTRO_DIST_FORCE_COLLECTIVES") == "1"
+
+
+def _alone(world: int) -> bool:
+    if world > 1:
+        return False
+    d = _dist()
+    return not (FORCE_COLLECTIVES and d.is_available() and d.is_initialized())
+
+
 def global_max(local_max):
     """All-reduce(MAX) of a 0-d/1-d tensor across ranks (identity when not distributed)."""
     d = _dist()
     world, _ = world_info()
-    if world > 1:
+    if not _alone(world):
         t, staged = _comm_tensor(local_max)                  # RCCL reduces device memory only: a host tensor goes through this rank's GPU
         d.all_reduce(t, op=d.ReduceOp.MAX)
         if staged:
@@ -80,7 +95,7 @@ def all_agree(ok: bool) -> bool:
     so that none of them walks into a collective the others have left."""
     d = _dist()
     world, _ = world_info()
-    if world == 1:
+    if _alone(world):
         return bool(ok)
     import torch
     flag, _ = _comm_tensor(torch.tensor([1 if ok else 0], dtype=torch.int32))
@@ -111,33 +126,84 @@ def gather_equal(t, dst: int | None = None):
     import torch
     d = _dist()
     world, rank = world_info()
-    if world == 1:
+    if _alone(world):
         return [t]
     if dst is None:
         ct, staged = _comm_tensor(t.contiguous())
         out = [torch.empty_like(ct) for _ in range(world)]
         d.all_gather(out, ct)
         return [o.cpu() for o in out] if staged else out
-    parts = gather_to_root([t], dst, shapes=[[tuple(t.shape)]] * world)
+    parts = gather_to_root([t], dst, shapes=[[(tuple(t.shape), t.dtype)]] * world)
     return [parts[r][0] for r in range(world)] if rank == dst else None
 
 
-def gather_to_root(tensors, dst: int = 0, shapes=None):
+def _dtype_name(dt) -> str:
+    return str(dt).replace("torch.", "")
+
+
+def _as_dtype(name):
+    import torch
+    if isinstance(name, torch.dtype):
+        return name
+    dt = getattr(torch, _dtype_name(name), None)
+    if not isinstance(dt, torch.dtype):
+        raise ValueError(f"gather_to_root: unknown dtype {name!r} in the shape table")
+    return dt
+
+
+def _split_entry(e):
+    """A shape-table entry is ``shape`` or ``(shape, dtype)`` (dtype a torch.dtype or its name) -> (shape, dtype | None)."""
+    if len(e) == 2 and isinstance(e[0], (tuple, list)) and not isinstance(e[1], (int, np.integer)):
+        return tuple(int(v) for v in e[0]), _as_dtype(e[1])
+    return tuple(int(v) for v in e), None
+
+
+# dtype codes for the one small collective that settles a table given without dtypes (0: this rank sends nothing, -1: mixed)
+_DTYPE_CODES = ("float32", "float64", "float16", "bfloat16", "int8", "uint8", "int16", "int32", "int64", "bool", "complex64", "complex128")
+
+
+def gather_to_root(tensors, dst: int = 0, shapes=None, checked: bool = False):
     """Ragged gather by direct peer sends (RCCL has no gatherv): every rank sends its tensors to ``dst``.
 
-    ``shapes[r]`` lists the shapes rank ``r`` sends; when None they are exchanged first with
-    ``all_gather_object``.  The sends and receives of a rank are posted as ONE batch (``batch_isend_irecv``), so under
-    RCCL the root's seven inbound xGMI links carry their shards concurrently instead of one peer after the other.
-    Host tensors are staged through the rank's GPU when the backend is RCCL and come back as host tensors.
+    ``shapes[r]`` lists what rank ``r`` sends, one entry per tensor: ``(shape, dtype)`` -- then nothing is exchanged before the
+    sends -- or a bare ``shape``; when ``shapes`` is None the table (shapes and dtypes) is exchanged first with ``all_gather_object``.
+    The root sizes every receive buffer with the SENDER's dtype: a peer whose products are float64 while the root holds
+    float32 (or nothing) arrives intact.  A table of bare shapes says nothing about dtypes, so the ranks settle them with one
+    tiny all-gather of dtype codes first (a rank whose own tensors are of several dtypes, or two ranks that disagree, make
+    EVERY rank raise -- before any send is posted, because a mismatched pair of P2P operations is wrong bytes under gloo and a
+    hang under RCCL).  The sends and receives of a rank are posted as ONE batch (``batch_isend_irecv``), so under RCCL the
+    root's seven inbound xGMI links carry their shards concurrently instead of one peer after the other.  Host tensors are
+    staged through the rank's GPU when the backend is RCCL and come back as host tensors.
+    Tensors that do not match their row of the table make every rank raise together (one all-reduce, skipped with
+    ``checked=True`` when the caller's ranks have already agreed on exactly that).
     Returns on ``dst`` a list (per rank) of lists of tensors, elsewhere None."""
     import torch
     d = _dist()
     world, rank = world_info()
-    if world == 1:
+    if _alone(world):
         return [list(tensors)]
     if shapes is None:
         shapes = [None] * world
-        d.all_gather_object(shapes, [tuple(t.shape) for t in tensors])
+        d.all_gather_object(shapes, [(tuple(t.shape), _dtype_name(t.dtype)) for t in tensors])
+    table = [[_split_entry(e) for e in shapes[r]] for r in range(world)]
+    if any(dt is None for row in table for _, dt in row):
+        mine = {_dtype_name(t.dtype) for t in tensors}
+        code = 0 if not mine else (_DTYPE_CODES.index(next(iter(mine))) + 1 if len(mine) == 1 and next(iter(mine)) in _DTYPE_CODES else -1)
+        ct, _ = _comm_tensor(torch.tensor([code], dtype=torch.int32))
+        codes = [torch.empty_like(ct) for _ in range(world)]
+        d.all_gather(codes, ct)
+        codes = [int(c.cpu()[0]) for c in codes]             # the same list on every rank: they all raise, or none does
+        used = {c for c in codes if c != 0}
+        if -1 in used or len(used) > 1:
+            raise ValueError("gather_to_root: a shape table without dtypes needs ONE dtype on every rank; got "
+                             + ", ".join("none" if c == 0 else "mixed" if c < 0 else _DTYPE_CODES[c - 1] for c in codes)
+                             + " -- pass (shape, dtype) entries")
+        common = _as_dtype(_DTYPE_CODES[used.pop() - 1]) if used else torch.float32
+        table = [[(s, common if dt is None else dt) for s, dt in row] for row in table]
+    own = [(tuple(t.shape), t.dtype) for t in tensors]
+    if not checked and not all_agree(own == table[rank]):    # one all-reduce; ``checked=True``: the caller's ranks have agreed already
+        raise ValueError(f"gather_to_root: the tensors do not match the shape table" +
+                         (f" (rank {rank} holds {own}, the table says {table[rank]})" if own != table[rank] else " (on another rank)"))
     staged_any = False
     comm = []
     for t in tensors:
@@ -145,7 +211,6 @@ def gather_to_root(tensors, dst: int = 0, shapes=None):
         staged_any |= staged
         comm.append(ct)
     if rank == dst:
-        dtype = comm[0].dtype if comm else torch.float32
         if comm:
             device = comm[0].device
         else:
@@ -156,7 +221,7 @@ def gather_to_root(tensors, dst: int = 0, shapes=None):
             if r == dst:
                 out.append(list(tensors))
                 continue
-            bufs = [torch.empty(s, dtype=dtype, device=device) for s in shapes[r]]
+            bufs = [torch.empty(s, dtype=dt, device=device) for s, dt in table[r]]
             ops += [d.P2POp(d.irecv, b, r) for b in bufs if b.numel()]
             out.append(bufs)
         if ops:

@@ -215,13 +215,13 @@ def sharded_sweep(clips, fs: float, n_ffts: Sequence[int], hops: Sequence[int], 
         # every rank can derive every shape: frames follow from (n_samples, n_fft, hop) -- with nperseg clamped to the clip length, as
         # the device call clamps it -- and clips from the block table.  A product of another shape would leave the root waiting for
         # bytes that never come (or a sender stuck): refuse it here, on every rank alike.
-        shapes = [[(ranges[r][1] - ranges[r][0], sweep_frames(n_samples, n, h)) if ranges[r][1] > ranges[r][0] else (0, 0)
+        shapes = [[((ranges[r][1] - ranges[r][0], sweep_frames(n_samples, n, h)) if ranges[r][1] > ranges[r][0] else (0, 0), torch.float32)
                    for (n, h), ranges in blocks.items()] for r in range(world)]
-        bad = [(pair, tuple(m.shape), tuple(want)) for m, want, pair in zip(mine, shapes[rank], blocks) if tuple(m.shape) != tuple(want)]
+        bad = [(pair, (tuple(m.shape), m.dtype), want) for m, want, pair in zip(mine, shapes[rank], blocks) if (tuple(m.shape), m.dtype) != want]
         if not sdist.all_agree(not bad):                     # every rank leaves here together, whichever of them holds the odd product
             raise ValueError("sweep products do not have the shapes the gather expects" +
                              (f": item {bad[0][0]} has {bad[0][1]}, expected {bad[0][2]}" if bad else " (on another rank)"))
-        gathered = sdist.gather_to_root(mine, dst=dst, shapes=shapes)
+        gathered = sdist.gather_to_root(mine, dst=dst, shapes=shapes, checked=True)
     finally:
         if run is not None and hasattr(run, "close"):
             run.close()

@@ -410,6 +410,35 @@ GLOO_SCRIPT = textwrap.dedent('''
     except ValueError:
         pass
     assert sd.all_agree(True) and not sd.all_agree(rank == 0)
+    # gather_to_root sizes a receive buffer with the SENDER's dtype: rank 1 sends float64 (and an int16 block) while the root
+    # holds float32 / nothing -- with the table exchanged, and with a table of (shape, dtype) entries given by the caller
+    f64 = torch.arange(6, dtype=torch.float64).reshape(2, 3) / 7.0
+    i16 = torch.arange(-3, 4, dtype=torch.int16)
+    for table in (None, [[((4,), torch.float32)], [((2, 3), "float64"), ((7,), torch.int16)]]):
+        mine = [torch.full((4,), 0.5, dtype=torch.float32)] if rank == 0 else [f64, i16]
+        got = sd.gather_to_root(mine, dst=0, shapes=table)
+        if rank == 0:
+            assert got[1][0].dtype == torch.float64 and torch.equal(got[1][0], f64), got[1][0]
+            assert got[1][1].dtype == torch.int16 and torch.equal(got[1][1], i16)
+        else:
+            assert got is None
+    got = sd.gather_to_root([] if rank == 0 else [f64], dst=0)                       # the root holds nothing at all
+    assert got is None if rank else (got[0] == [] and torch.equal(got[1][0], f64))
+    # a table of bare shapes: one dtype everywhere is settled by a small all-gather (the root's own dtype no longer decides) ...
+    got = sd.gather_to_root([] if rank == 0 else [f64], dst=0, shapes=[[], [(2, 3)]])
+    assert got is None if rank else (got[1][0].dtype == torch.float64 and torch.equal(got[1][0], f64))
+    # ... and ranks that disagree (f32 on the root, f64 on the peer) all raise, before any send is posted
+    try:
+        sd.gather_to_root([torch.zeros(2, 3)] if rank == 0 else [f64], dst=0, shapes=[[(2, 3)], [(2, 3)]])
+        raise SystemExit("rank %d: mixed dtypes under a table without dtypes were not refused" % rank)
+    except ValueError:
+        pass
+    # tensors that contradict the table: every rank raises together, whichever rank holds them
+    try:
+        sd.gather_to_root([torch.zeros(2, 3)] if rank == 0 else [f64], dst=0, shapes=[[((2, 3), "float32")], [((2, 3), "float32")]])
+        raise SystemExit("rank %d: a tensor that contradicts the table was not refused" % rank)
+    except ValueError:
+        pass
     dist.barrier(); dist.destroy_process_group()
     os.write(1, ("rank %d ok" % rank + chr(10)).encode())   # one write per rank: print() pieces of two ranks can interleave
 ''')
@@ -547,3 +576,55 @@ def test_bench_spawns_its_own_ranks_and_refuses_a_wrong_world():
                        env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
     assert not any(ln.startswith("{") for ln in r.stdout.splitlines())
+
+
+def test_hip_runtime_preload_checks_the_soname(tmp_path):
+    """torch's bundled HIP runtime is preloaded only when its SONAME is the name libspectro.so needs (both read from
+    the ELF files); a torch built for another ROCm major is left alone, with a warning.  Child processes: the decision is made
+    once per process, at the first lib() call."""
+    sys.path.insert(0, PKG)
+    from spectro import _capi
+    soname, needed = _capi._elf_dynamic(_capi.LIB_PATH)
+    hip = [n for n in needed if n.startswith("libamdhip64.so")]
+    assert len(hip) == 1 and "libstdc++.so.6" in needed
+    # a stand-in "torch" whose bundled runtime carries another SONAME (a shared object built here with gcc)
+    fake = tmp_path / "torch"
+    (fake / "lib").mkdir(parents=True)
+    (fake / "__init__.py").write_text("raise ImportError('the stand-in torch must never be imported')\n")
+    src = tmp_path / "x.c"
+    src.write_text("int sg_fake_runtime(void) { return 6; }\n")
+    subprocess.run(["gcc", "-shared", "-fPIC", "-Wl,-soname,libamdhip64.so.6", str(src), "-o", str(fake / "lib" / "libamdhip64.so")], check=True)
+    assert _capi._elf_dynamic(str(fake / "lib" / "libamdhip64.so"))[0] == "libamdhip64.so.6"
+    code = textwrap.dedent('''
+        import sys, warnings
+        sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])      # the stand-in torch shadows the real one
+        from spectro import _capi
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            try:
+                _capi.lib()
+                err = ""
+            except ImportError as e:
+                err = str(e)
+        print("choice=%s warned=%d err=%s" % (_capi.hip_runtime["choice"], sum("cannot be shared" in str(x.message) for x in w), err[:60]))
+        with open("/proc/self/maps") as fh:
+            print("mapped_fake=%d" % sum("libamdhip64.so" in l and sys.argv[1] in l for l in fh))
+    ''')
+    env = {k: v for k, v in os.environ.items() if k != "SPECTRO_HIP_RUNTIME"}
+    r = subprocess.run([sys.executable, "-c", code, str(tmp_path), PKG], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stderr[-800:]
+    assert "choice=system warned=1 err=" in r.stdout and "mapped_fake=0" in r.stdout, r.stdout
+    r = subprocess.run([sys.executable, "-c", code, str(tmp_path), PKG], capture_output=True, text=True, env=dict(env, SPECTRO_HIP_RUNTIME="torch"), timeout=120)
+    assert r.returncode == 0 and "err=SPECTRO_HIP_RUNTIME=torch" in r.stdout, r.stdout + r.stderr[-400:]
+    # the real torch of this image: its SONAME matches, so it is the one mapped (and said so)
+    real = textwrap.dedent('''
+        import sys
+        sys.path.insert(0, sys.argv[1])
+        from spectro import _capi
+        _capi.lib()
+        print("choice=%s path=%s" % (_capi.hip_runtime["choice"], _capi.hip_runtime["path"]))
+    ''')
+    r = subprocess.run([sys.executable, "-c", real, PKG], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0 and "choice=torch path=" in r.stdout and "torch/lib/libamdhip64.so" in r.stdout, r.stdout + r.stderr[-400:]
+    r = subprocess.run([sys.executable, "-c", real, PKG], capture_output=True, text=True, env=dict(env, SPECTRO_HIP_RUNTIME="system"), timeout=120)
+    assert r.returncode == 0 and "choice=system path=None" in r.stdout, r.stdout + r.stderr[-400:]
