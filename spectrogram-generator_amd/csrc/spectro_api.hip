@@ -48,6 +48,13 @@ static bool rbigd_ok(const sg_plan& p) {
            (p.mode == SG_MODE_PSD || p.mode == SG_MODE_MAGNITUDE);
 }
 
+// even transform lengths that are not a power of two, up to 2048: the register chirp-z kernel (stft_rblue.hip)
+static bool rblue_ok(const sg_plan& p) {
+    return p.dtype == SG_F32 && p.nperseg == p.nfft && p.nfft % 2 == 0 && !is_pow2(p.nfft) && p.nfft >= 6 && p.nfft <= 2048 &&
+           (p.detrend == SG_DETREND_NONE || p.detrend == SG_DETREND_CONSTANT) &&
+           (p.mode == SG_MODE_PSD || p.mode == SG_MODE_MAGNITUDE);
+}
+
 static bool stockham_ok(const sg_plan& p) {
     if (!is_pow2(p.nfft) || p.nfft < 2) return false;
     // LDS need of the largest case: one frame per workgroup, two nfft-real buffers + reduction scratch
@@ -96,7 +103,8 @@ static int build_common_tables(sg_plan& p, const std::vector<double>& window) {
 }
 
 static void free_tables(sg_plan* p) {
-    void** ptrs[] = {&p->win_dev, &p->tw_dev, &p->r8_tw_dev, &p->r8_win_dev, &p->bs_chirp_dev, &p->bs_filter_dev, &p->bs_tw_dev};
+    void** ptrs[] = {&p->win_dev, &p->tw_dev, &p->r8_tw_dev, &p->r8_win_dev, &p->bs_chirp_dev, &p->bs_filter_dev, &p->bs_tw_dev,
+                     &p->rb_wc_dev, &p->rb_filt_dev, &p->rb_stw_dev, &p->rb_tw_dev};
     for (void** q : ptrs) {
         if (*q) (void)hipFree(*q);
         *q = nullptr;
@@ -150,6 +158,26 @@ static int run_converted(const sg_plan* plan, StftArgs& a) {
     return rc;
 }
 
+// The fused band power of a chirp-z plan on a call its register kernel cannot take (odd hop, unaligned clips): full spectra by the LDS
+// kernel into a block of their own, then the band sums.  A rare path (the register kernel serves every even hop): the block is a plain
+// hipMalloc / hipFree pair -- the stream's workspace may be holding the float copy of an int16 call around this one.
+static int band_via_spectrum(const sg_plan* plan, StftArgs& a) {
+    const int nbins = plan->nfft / 2 + 1;
+    void* spec = nullptr;
+    SG_HIP(hipMalloc(&spec, static_cast<size_t>(a.n_clips) * a.n_frames * nbins * sizeof(float)));
+    StftArgs f = a;
+    f.band_mode = 0;
+    f.out = spec;
+    f.out_clip_stride = a.n_frames * nbins;
+    int rc = launch_bluestein(*plan, f);
+    for (int c = 0; rc == SG_OK && c < a.n_clips; ++c)
+        rc = sg_band_sum(static_cast<const float*>(spec) + static_cast<int64_t>(c) * a.n_frames * nbins, SG_F32, a.n_frames, nbins, a.k_lo, a.k_hi,
+                         static_cast<float*>(a.out) + static_cast<int64_t>(c) * a.out_clip_stride, a.stream);
+    if (rc == SG_OK) { const hipError_t e = hipStreamSynchronize(a.stream); if (e != hipSuccess) rc = hip_fail(e, "band_via_spectrum"); }
+    (void)hipFree(spec);
+    return rc;
+}
+
 static int run_stft(const sg_plan* plan, StftArgs& a) {
     if (!plan) { set_error("null plan"); return SG_ERR_ARG; }
     if (a.n_clips < 0 || a.n_samples < 0) { set_error("negative sizes"); return SG_ERR_ARG; }
@@ -167,6 +195,7 @@ static int run_stft(const sg_plan* plan, StftArgs& a) {
     if (a.in_i16 && (plan->kernel == Kernel::RSMALL || plan->kernel == Kernel::RBIG) && plan->hop % 2 == 0 &&
         (a.clip_stride % 2 == 0 || a.n_clips == 1) && static_cast<int64_t>(a.n_clips) * a.n_samples >= (1 << 18))
         return run_converted(plan, a);
+    if (plan->kernel == Kernel::RBLUE && a.in_i16) return run_converted(plan, a);     // neither chirp-z kernel loads int16
     switch (plan->kernel) {
         case Kernel::R8X3: return launch_r8x3(*plan, a);
         case Kernel::R8X3D: return r8x3_f64_can_run(*plan, a) ? launch_r8x3_f64(*plan, a) : launch_stockham(*plan, a);
@@ -175,6 +204,8 @@ static int run_stft(const sg_plan* plan, StftArgs& a) {
         case Kernel::RBIGD: return rbig_f64_can_run(*plan, a) ? launch_rbig_f64(*plan, a) : launch_stockham(*plan, a);
         case Kernel::STOCKHAM: return launch_stockham(*plan, a);
         case Kernel::BLUESTEIN: return launch_bluestein(*plan, a);
+        // odd hops / unaligned clips, GUI-sized int16 calls: the LDS chirp-z kernel (its tables are built with the plan); it writes full spectra only
+        case Kernel::RBLUE: return rblue_can_run(*plan, a) ? launch_rblue(*plan, a) : a.band_mode ? band_via_spectrum(plan, a) : launch_bluestein(*plan, a);
     }
     return SG_ERR_UNSUPPORTED;
 }
@@ -332,6 +363,10 @@ int sg_plan_create(sg_plan** plan, int nperseg, int nfft, int hop, const double*
             rc = build_rbig_f64_tables(*p);
         } else if (stockham_ok(*p)) {
             p->kernel = Kernel::STOCKHAM;
+        } else if (rblue_ok(*p)) {
+            p->kernel = Kernel::RBLUE;
+            rc = build_rblue_tables(*p, w);
+            if (rc == SG_OK) rc = build_bluestein_tables(*p);     // the fallback of calls the register kernel cannot take
         } else {
             p->kernel = Kernel::BLUESTEIN;
             rc = build_bluestein_tables(*p);
@@ -377,6 +412,7 @@ const char* sg_plan_kernel(const sg_plan* plan) {
         case Kernel::RBIGD: return "rbigd";
         case Kernel::STOCKHAM: return "stockham";
         case Kernel::BLUESTEIN: return "bluestein";
+        case Kernel::RBLUE: return "rblue";
     }
     return "";
 }
@@ -416,6 +452,12 @@ int sg_plan_force_kernel(sg_plan* plan, const char* name) {
     if (!strcmp(name, "stockham")) {
         if (!stockham_ok(*plan)) { set_error("plan cannot run on stockham"); return SG_ERR_UNSUPPORTED; }
         plan->kernel = Kernel::STOCKHAM;
+        return SG_OK;
+    }
+    if (!strcmp(name, "rblue")) {
+        if (!rblue_ok(*plan)) { set_error("plan cannot run on rblue"); return SG_ERR_UNSUPPORTED; }
+        if (!plan->rb_wc_dev) { set_error("rblue tables are built with the plan only"); return SG_ERR_UNSUPPORTED; }
+        plan->kernel = Kernel::RBLUE;
         return SG_OK;
     }
     if (!strcmp(name, "bluestein")) {

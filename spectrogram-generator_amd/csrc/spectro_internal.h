@@ -19,7 +19,7 @@ int hip_fail(hipError_t e, const char* what);   // records message, returns SG_E
         if (e__ != hipSuccess) return ::sg::hip_fail(e__, #call);      \
     } while (0)
 
-enum class Kernel { R8X3, R8X3D, RSMALL, RBIG, RBIGD, STOCKHAM, BLUESTEIN };
+enum class Kernel { R8X3, R8X3D, RSMALL, RBIG, RBIGD, STOCKHAM, BLUESTEIN, RBLUE };
 
 }  // namespace sg
 
@@ -42,6 +42,11 @@ struct sg_plan {
     void* bs_chirp_dev = nullptr;   // b[n] = exp(-i*pi*n^2/nfft), n < nfft
     void* bs_filter_dev = nullptr;  // FFT_L of conj-chirp filter, bit-reversed order, pre-scaled by 1/L
     void* bs_tw_dev = nullptr;      // exp(-2*pi*i*k/L), k < L/2
+    // register chirp-z tables (RBLUE, stft_rblue.hip): window pairs + chirp, filter spectrum, split twiddles, per-lane FFT twiddles
+    void* rb_wc_dev = nullptr;
+    void* rb_filt_dev = nullptr;
+    void* rb_stw_dev = nullptr;
+    void* rb_tw_dev = nullptr;
 };
 
 namespace sg {
@@ -82,6 +87,8 @@ int launch_rbig_f64(const sg_plan& p, const StftArgs& a);
 bool rbig_f64_can_run(const sg_plan& p, const StftArgs& a);
 int launch_stockham(const sg_plan& p, const StftArgs& a);
 int launch_bluestein(const sg_plan& p, const StftArgs& a);
+int launch_rblue(const sg_plan& p, const StftArgs& a);
+bool rblue_can_run(const sg_plan& p, const StftArgs& a);
 
 int build_r8x3_tables(sg_plan& p, const std::vector<double>& window);
 int build_r8x3_f64_tables(sg_plan& p);
@@ -89,5 +96,6 @@ int build_rsmall_tables(sg_plan& p);
 int build_rbig_tables(sg_plan& p);
 int build_rbig_f64_tables(sg_plan& p);
 int build_bluestein_tables(sg_plan& p);
+int build_rblue_tables(sg_plan& p, const std::vector<double>& window);
 
 }  // namespace sg

@@ -71,7 +71,8 @@ CASES = [  # dtype, nperseg, hop, window, forced family, expected family
     ("f32", 256, 64, "hann", None, "rsmall"),
     ("f32", 4096, 1024, "hann", None, "rbig"),
     ("f32", 1024, 256, ("tukey", 0.25), "stockham", "stockham"),
-    ("f32", 1000, 250, "hann", None, "bluestein"),
+    ("f32", 1000, 250, "hann", None, "rblue"),
+    ("f32", 1000, 250, "hann", "bluestein", "bluestein"),
     ("f64", 1024, 256, ("tukey", 0.25), None, "r8x3d"),
 ]
 

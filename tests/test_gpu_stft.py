@@ -911,3 +911,96 @@ def test_c_client_matches_python_path_and_oracle(tmp_path):
         assert_spec_close(got, s, tol_frame=2e-6, tol_norm=1e-6, time_axis=-1)
         fo, to, so = orc.spectrogram(x, fs=fs, nperseg=nperseg)
         assert_spec_close(got, so, time_axis=-1)
+
+
+@pytest.mark.parametrize("n,hop,detrend,mode,window", [
+    (1000, 250, "constant", "psd", "hann"), (1000, 876, "constant", "psd", ("tukey", 0.25)), (960, 240, False, "magnitude", "hann"),
+    (96, 24, "constant", "psd", ("tukey", 0.25)), (160, 140, "constant", "psd", "hann"), (6, 2, "constant", "psd", "boxcar"),
+    (34, 30, False, "psd", "hann"), (1022, 2, "constant", "psd", "hann"), (1026, 256, "constant", "psd", "hann"),
+    (1504, 1316, "constant", "psd", ("tukey", 0.25)), (2046, 512, "constant", "magnitude", "hann"), (2016, 64, False, "psd", "boxcar")])
+def test_rblue_kernel(sp, n, hop, detrend, mode, window):
+    """Even nperseg that is not a power of two (the GUI's spin box steps by 32, GUI.py:87-89): the register chirp-z kernel
+    (stft_rblue.hip, round 4) against the oracle -- several clips incl. all-zero and constant ones, a ragged tail -- and against the
+    LDS chirp-z kernel of the same plan."""
+    from spectro import _capi
+    from spectro.signal import plan_for
+    from spectro.windows import get_window
+    rng = np.random.default_rng(n + hop)
+    N = n + hop * 23 + 6
+    x = (rng.standard_normal((5, N)) * 0.4 + 0.2).astype(np.float32)
+    x[2] = 0.0
+    x[3] = -7.5
+    kw = dict(fs=48000.0, nperseg=n, window=window, noverlap=n - hop, detrend=detrend, mode=mode)
+    plan = plan_for(get_window(window, n), n, n, hop, _capi.DETREND[detrend], 48000.0, 0, _capi.MODE[mode], _capi.F32)
+    assert plan.kernel == "rblue"
+    f, t, s = sp.spectrogram(x, **kw)
+    fo, to, so = orc.spectrogram(x, **kw)
+    np.testing.assert_array_equal(f, fo)
+    np.testing.assert_array_equal(t, to)
+    assert s.dtype == np.float32 and s.shape == so.shape
+    floor = 1e-3 if mode == "psd" else 1e-3 ** 0.5
+    keep = [0, 1, 4] if detrend else [0, 1, 3, 4]              # (a detrended constant clip is rounding noise in both: checked below)
+    assert_spec_close(s[keep], so[keep], time_axis=-1, bin_floor=floor)
+    assert np.all(s[2] == 0.0)
+    if detrend:
+        assert np.abs(s[3]).max() <= 1e-7 * np.abs(s[0]).max()
+    plan.force_kernel("bluestein")
+    try:
+        _, _, s_lds = sp.spectrogram(x, **kw)
+    finally:
+        plan.force_kernel("rblue")
+    assert_spec_close(s[keep], s_lds[keep], time_axis=-1, bin_floor=floor)
+
+
+@pytest.mark.parametrize("n,hop", [(1000, 250), (96, 32), (1504, 188)])
+def test_rblue_band_power_int16_and_fallbacks(sp, n, hop):
+    """The register chirp-z kernel's other entry points: fused band power (A11) == the sum over the written bins; int16 batches
+    (converted once on the device); calls it cannot take -- odd hop, clips at an odd stride -- run the LDS kernel, spectra and band
+    power alike, with the same values."""
+    from spectro import _capi
+    from spectro.signal import plan_for
+    from spectro.windows import get_window
+    rng = np.random.default_rng(n * 7 + hop)
+    ns = n + hop * 21 + 2
+    x = (rng.standard_normal((4, ns)) * 0.3 + 0.5).astype(np.float32)
+    plan = plan_for(get_window("hann", n), n, n, hop, 1, 48000.0, 0, 0, _capi.F32)
+    assert plan.kernel == "rblue"
+    nfr, nb = plan.n_frames(ns), n // 2 + 1
+    d_in, d_s, d_bp = _capi.DeviceBuffer(x.nbytes), _capi.DeviceBuffer(4 * nfr * nb * 4), _capi.DeviceBuffer(4 * nfr * 4)
+    d_in.upload(x)
+    plan.stft(d_in.ptr, ns, ns, 4, d_s.ptr, nfr * nb)
+    spec = np.empty((4, nfr, nb), np.float32)
+    d_s.download(spec)
+    _capi.stream_sync()
+    h = n // 2
+    for k_lo, k_hi in [(0, h), (1, 7), (h // 2, h // 2), (0, 0), (h, h), (33, h - 1)]:
+        _capi.check(_capi.lib().sg_memset(C.c_void_p(d_bp.ptr), 0xFF, 4 * nfr * 4, None))
+        plan.band_power(d_in.ptr, ns, ns, 4, k_lo, k_hi, d_bp.ptr, nfr)
+        bp = np.empty((4, nfr), np.float32)
+        d_bp.download(bp)
+        _capi.stream_sync()
+        ref = spec[:, :, k_lo:k_hi + 1].astype(np.float64).sum(-1)
+        assert np.all(np.abs(bp - ref) <= 2e-6 * spec.astype(np.float64).sum(-1) + 1e-30), (k_lo, k_hi)
+    # int16 PCM: converted on the device, then the register kernel -- bit-identical to the float call on the same values
+    xi = np.round(x * 8000).astype(np.int16)
+    _, _, s_i = sp.spectrogram(xi, fs=48000.0, nperseg=n, window="hann", noverlap=n - hop)
+    _, _, s_f = sp.spectrogram(xi.astype(np.float32), fs=48000.0, nperseg=n, window="hann", noverlap=n - hop)
+    np.testing.assert_array_equal(s_i, s_f)
+    # odd hop, and clips at an odd stride (ns - 1 samples of each row): the LDS kernel takes the call
+    for kw, xs in ((dict(noverlap=n - hop - 1), x), (dict(noverlap=n - hop), x[:, :ns - 1] if (ns - 1) % 2 else x[:, :ns - 2])):
+        _, _, s1 = sp.spectrogram(xs, fs=48000.0, nperseg=n, window="hann", **kw)
+        _, _, so = orc.spectrogram(xs, fs=48000.0, nperseg=n, window="hann", **kw)
+        assert_spec_close(s1, so, time_axis=-1)
+    d2 = _capi.DeviceBuffer(4 * nfr * 4)
+    plan_odd = plan_for(get_window("hann", n), n, n, hop + 1, 1, 48000.0, 0, 0, _capi.F32)
+    nf2 = plan_odd.n_frames(ns)
+    plan_odd.band_power(d_in.ptr, ns, ns, 4, 1, 7, d2.ptr, nf2)
+    raw = np.empty(4 * nfr, np.float32)
+    d2.download(raw)
+    _capi.stream_sync()
+    _, _, so = orc.spectrogram(x, fs=48000.0, nperseg=n, window="hann", noverlap=n - hop - 1)
+    ref = so[:, 1:8, :].sum(axis=1)
+    got = raw[:4 * nf2].reshape(4, nf2)
+    assert np.all(np.abs(got - ref) <= 1e-4 * np.abs(ref) + 1e-12)
+    for b in (d_in, d_s, d_bp, d2):
+        b.free()

@@ -8,7 +8,7 @@ P=$R/spectrogram-generator_amd
 mkdir -p $P/lib_$name
 base=$(basename $src .hip); base=${base%_tmp}
 noslp=""
-case $base in stft_r8x3|stft_rsmall|stft_rbig|stft_mel_fused) noslp="-fno-slp-vectorize";; esac
+case $base in stft_r8x3|stft_rsmall|stft_rbig|stft_rblue|stft_mel_fused) noslp="-fno-slp-vectorize";; esac
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -fno-gpu-rdc -Wno-unused-function -Wno-unused-result $noslp $defs \
   -I $R/include -I $P/csrc -c $src -o $P/lib_$name/$base.o
 objs=""
