@@ -28,15 +28,6 @@ namespace {
 
 using namespace wavefft;
 
-__device__ __forceinline__ void xfence() {
-#if SG_RBIG_FENCE == 2
-    wave_lds_fence();
-#elif SG_RBIG_FENCE == 1
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#endif
-}
-
 constexpr int kS1 = 72, kS2 = 66;
 typedef float v4f __attribute__((ext_vector_type(4)));
 // two neighbouring float2 of the tables in one 16-byte LDS read (volatile for the reason lds_get is, fft_wave.h)
@@ -44,9 +35,7 @@ __device__ __forceinline__ v4f lds_get2(const float2* p) { return *(__attribute_
 // waves per workgroup (the LDS tables are shared by the workgroup): T = 4 -> one workgroup of 12 waves per CU
 // (43 KiB of tables + 12 x 4.5 KiB, 142 VGPRs = 3 waves/SIMD); T = 2 -> two workgroups of 8 (21 + 36 KiB each)
 #ifndef SG_RBIG_PRIO
-#define SG_RBIG_PRIO 1          // 1: wave priority rises along a frame (pass 1 -> stores), as in stft_r8x3; 0 = off;
-                                // 2: priority 3 while a wave issues an LDS exchange, 0 in its VALU passes (tools/ubench/phase_model.hip: the LDS pipe
-                                //    is kept busy, -10 % in the model); 3: rising as in 1, and 3 during the exchanges
+#define SG_RBIG_PRIO 1          // wave priority rises along a frame (pass 1 -> stores), as in stft_r8x3; 0 = off
 #endif
 #ifndef SG_RBIG_TW2_REG
 #define SG_RBIG_TW2_REG 1          // the seven pass-2 twiddles in VGPRs where the occupancy has room (T = 4 sliding: 236 -> 254 of 256): 28 LDS reads fewer per
@@ -56,18 +45,11 @@ __device__ __forceinline__ v4f lds_get2(const float2* p) { return *(__attribute_
 #define SG_RBIG_B128 1             // window, t1 and t3 tables keep rows 2m, 2m+1 of a lane side by side: one ds_read_b128 per two rows (a b128 read moves twice
                                    // the bytes in 1.3x the time); -1 ... -2.7 % on every shape (profiles/r03_rbig_b128_tables.txt); 0 = one ds_read_b64 per row
 #endif
-#ifndef SG_RBIG_FENCE
-#define SG_RBIG_FENCE 2            // between an exchange's stores and its loads: 2 = wave_lds_fence() (compiler barrier for everything), 1 = memory fences
-                                   // only (VALU may be scheduled across), 0 = nothing (the LDS accesses are volatile: they keep their order anyway)
-#endif
 #ifndef SG_RBIG4_OCC
 #define SG_RBIG4_OCC 3            // waves per SIMD the T = 4 kernel is compiled for
 #endif
 // H > 0 (the sample window slides in registers, see the frame loop): T = 4 keeps 32 more float2 per lane -> 2 waves per SIMD
-#ifndef SG_RBIG4_SLIDE_OCC
-#define SG_RBIG4_SLIDE_OCC 2      // waves per SIMD of the T = 4 sliding form
-#endif
-template <int T, int H> struct OccFor { static constexpr int value = T == 4 ? (H > 0 ? SG_RBIG4_SLIDE_OCC : SG_RBIG4_OCC) : 4; };
+template <int T, int H> struct OccFor { static constexpr int value = T == 4 ? (H > 0 ? 2 : SG_RBIG4_OCC) : 4; };
 template <int T, int H> struct WavesFor { static constexpr int value = T == 4 ? 4 * OccFor<T, H>::value : 8; };
 constexpr int kSlabElems = 8 * kS1;                          // one 8-register exchange group (576 float2)
 
@@ -159,7 +141,7 @@ __global__ __launch_bounds__((64 * WavesFor<T, H>::value), (OccFor<T, H>::value)
     const float2* const x3b = buf + (256 - lane);            // - 64*(c - 4i)
 
     const float r0 = (MODE != 1 && lane == 0) ? 0.5f : 1.0f;
-    constexpr bool kTw2Reg = SG_RBIG_TW2_REG && T == 4 && H > 0 && SG_RBIG4_SLIDE_OCC == 2;
+    constexpr bool kTw2Reg = SG_RBIG_TW2_REG && T == 4 && H > 0;
     float2 t2r[kTw2Reg ? 7 : 1];
     if (kTw2Reg) {
 #pragma unroll
@@ -202,8 +184,6 @@ __global__ __launch_bounds__((64 * WavesFor<T, H>::value), (OccFor<T, H>::value)
 #endif
 
         if (SG_RBIG_PRIO) __builtin_amdgcn_s_setprio(0);
-#define SG_XPRIO(base, lds_phase) do { if (SG_RBIG_PRIO == 2) __builtin_amdgcn_s_setprio((lds_phase) ? 3 : 0); \
-                                       if (SG_RBIG_PRIO == 3) __builtin_amdgcn_s_setprio((lds_phase) ? 3 : (base)); } while (0)
         // ---- pass 1: R-point DFT over a = a0 + T*a1 --------------------------------------------------------
 #pragma unroll
         for (int a0 = 0; a0 < T; ++a0) {
@@ -236,19 +216,17 @@ __global__ __launch_bounds__((64 * WavesFor<T, H>::value), (OccFor<T, H>::value)
             for (int r1 = 0; r1 < 8; ++r1)
                 if (q + r1 > 0) d[q][r1] = cmul(d[q][r1], lds_get(t1 + 64 * (r1 + 8 * q - 1)));
 #endif
-        SG_XPRIO(0, true);
 #pragma unroll
         for (int q = 0; q < T; ++q) {                        // exchange 1, one group of 8 at a time through the slab
 #pragma unroll
             for (int r1 = 0; r1 < 8; ++r1) lds_put(x1w + 8 * r1, d[q][r1]);
-            xfence();
+            wave_lds_fence();
 #pragma unroll
             for (int b = 0; b < 8; ++b) d[q][b] = lds_get(x1r + b * kS1);
-            xfence();
+            wave_lds_fence();
         }
 
-        if (SG_RBIG_PRIO == 1) __builtin_amdgcn_s_setprio(1);
-        SG_XPRIO(1, false);
+        if (SG_RBIG_PRIO) __builtin_amdgcn_s_setprio(1);
         // ---- pass 2 ----------------------------------------------------------------------------------------------
 #pragma unroll
         for (int q = 0; q < T; ++q) {
@@ -257,7 +235,6 @@ __global__ __launch_bounds__((64 * WavesFor<T, H>::value), (OccFor<T, H>::value)
             for (int s = 1; s < 8; ++s) d[q][s] = cmul(d[q][s], kTw2Reg ? t2r[kTw2Reg ? s - 1 : 0] : lds_get(t2 + 64 * (s - 1)));
         }
         float2 e[T][8];                                      // pass-3 operands: e[q3][j]
-        SG_XPRIO(1, true);
 #pragma unroll
         for (int q3 = 0; q3 < T; ++q3) {                     // exchange 2: group q3 collects the (q, s) with (8q + R*s) / 64 == q3
 #pragma unroll
@@ -267,21 +244,19 @@ __global__ __launch_bounds__((64 * WavesFor<T, H>::value), (OccFor<T, H>::value)
                     const int uu = 8 * q + R * s;            // + r1 (= hi) < 8 never carries into the next 64
                     if (uu / 64 == q3) lds_put(x2w + (uu % 64), d[q][s]);
                 }
-            xfence();
+            wave_lds_fence();
 #pragma unroll
             for (int j = 0; j < 8; ++j) e[q3][j] = lds_get(x2r + j * kS2);
-            xfence();
+            wave_lds_fence();
         }
 
-        if (SG_RBIG_PRIO == 1) __builtin_amdgcn_s_setprio(2);
-        SG_XPRIO(2, false);
+        if (SG_RBIG_PRIO) __builtin_amdgcn_s_setprio(2);
         // ---- pass 3: d[q3][t] = Z[lane + 64*(q3 + T*t)] ---------------------------------------------------
 #pragma unroll
         for (int q3 = 0; q3 < T; ++q3) radix8(e[q3]);
 #define SG_Z(c) e[(c) % T][(c) / T]                          // Z[lane + 64*c]
 
-        if (SG_RBIG_PRIO == 1 || SG_RBIG_PRIO == 3) __builtin_amdgcn_s_setprio(3);
-        if (SG_RBIG_PRIO == 2) __builtin_amdgcn_s_setprio(1);
+        if (SG_RBIG_PRIO) __builtin_amdgcn_s_setprio(3);
         // ---- split pass + epilogue: lower blocks c (registers) pair with upper blocks R-1-c (and element 0 of
         //      block R-c) of the mirrored lane; four blocks per trip through the slab ------------------------------
 #pragma unroll
@@ -289,7 +264,7 @@ __global__ __launch_bounds__((64 * WavesFor<T, H>::value), (OccFor<T, H>::value)
 #pragma unroll
             for (int sl = 0; sl < 4; ++sl) lds_put(x3w + 64 * sl, SG_Z(R - 4 * i - 4 + sl));
             if (lane == 0) lds_put(buf + 256, i == 0 ? SG_Z(0) : SG_Z(R - 4 * i));   // i = 0: Z[M] := Z[0]
-            xfence();
+            wave_lds_fence();
             v4f cs2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) {
@@ -319,7 +294,7 @@ __global__ __launch_bounds__((64 * WavesFor<T, H>::value), (OccFor<T, H>::value)
                     orow[M - k] = pm;
                 }
             }
-            xfence();
+            wave_lds_fence();
         }
         {   // k = M/2: lane 0, block c = R/2
             const float zx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, SG_Z(R / 2).x), 0));
@@ -335,7 +310,6 @@ __global__ __launch_bounds__((64 * WavesFor<T, H>::value), (OccFor<T, H>::value)
             }
         }
 #undef SG_Z
-#undef SG_XPRIO
     };
 
     if constexpr (H == 0) {

@@ -13,7 +13,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 bad = 0
 fam = {}
 for it in range(cases):
-    nper = int(rng.choice([64, 128, 256, 256, 512, 512, 1024, 1024, 2048, 2048, 4096, 4096, 1000, 384, 6000]))      # 6000: chirp-z, f64 in the HBM workspace
+    nper = int(rng.choice([64, 128, 256, 256, 512, 512, 1024, 1024, 2048, 2048, 4096, 4096, 1000, 384, 6000, 96, 1504, 2016, 34, 960]))      # even non-powers of two up to 2048: the register chirp-z kernel (round 4);      # 6000: chirp-z, f64 in the HBM workspace
     r = rng.random()
     hop = int(rng.choice([64, 128, 256, 512])) if r < 0.5 else (nper - nper // 8 if r < 0.7 else int(rng.integers(1, nper + 1)))
     hop = max(1, min(hop, nper))
