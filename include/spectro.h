@@ -259,7 +259,13 @@ int sg_mel(const float* spec_dev, int64_t n_frames, int n_bins, const float* wei
  * SG_ERR_UNSUPPORTED otherwise (use sg_stft + sg_mel).  Weights/ranges as for sg_mel; weights_n_bins is the n_bins the
  * bank was packed for (sg_mel_pack_weights) and must equal the plan's nfft/2+1 (SG_ERR_ARG otherwise: the kernel indexes
  * the bank with the plan's row pitch).  Asynchronous.
+ * log_scale is a flags word here: SG_MEL_LOG (= 1, so a plain 0 / 1 keeps its meaning) | SG_MEL_FORM_WS (the wave-specialised
+ * kernel form: producer waves transform while consumer waves contract the previous tile) | SG_MEL_FORM_CONS4 (that form with four
+ * consumer waves instead of eight).  The forms compute the same values; the library itself reads no environment variable.
  */
+#define SG_MEL_LOG 1
+#define SG_MEL_FORM_WS 0x100
+#define SG_MEL_FORM_CONS4 0x200
 int sg_stft_mel(const sg_plan* plan, const float* x_dev, int64_t n_samples, int64_t clip_stride, int n_clips,
                 const float* packed_weights_dev, int weights_n_bins, int n_mels, const int* tile_k_lo,
                 const int* tile_k_hi, int log_scale, float* mel_dev, int64_t out_clip_stride, void* stream);

@@ -21,6 +21,8 @@ LIB = os.path.join(LIBDIR, "libspectro.so")
 SOURCES = ["host_shim.cpp", "spectro_api.hip", "stft_r8x3.hip", "stft_r8x3_f64.hip", "stft_rsmall.hip", "stft_rbig.hip", "stft_rbig_f64.hip", "stft_stockham.hip", "stft_bluestein.hip", "stft_rblue.hip", "epilogue.hip", "mel.hip", "stft_mel_fused.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-fno-gpu-rdc",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+if os.environ.get("SG_TUNING") == "1":          # the launch-time tuning variables of the A/B tools (csrc/spectro_internal.h: SG_TUNE_ENV); never in the product build
+    FLAGS.append("-DSG_TUNING=1")
 # Per-file extras.  stft_r8x3 is VALU-bound: gfx950 issues v_pk_*_f32 at half the rate of the plain ops
 # (tools/ubench/valu_rate.hip: 2.2 ns vs 1.2 ns per wave-instruction per SIMD), so SLP packing only adds
 # register-pair shuffles (v_pk_mov/v_mov) -- keep the scalar forms.

@@ -2,6 +2,7 @@
 // after scipy returns it: PlotEngine.py:114-131 (mask, normalise, dB, min-max), :238-241 (band
 // log-power features), :686-719 (absolute / relative band powers).  All HBM-bound; one pass each.
 #include "spectro_internal.h"
+#include <memory>
 
 #include <cstdint>
 #include <cstdlib>
@@ -338,17 +339,48 @@ inline int after_launch(const char* what) {
 namespace {
 struct StreamState {
     std::recursive_mutex mu;
+    int device = 0;
     void* scratch = nullptr;
     void* ws = nullptr; size_t ws_bytes = 0;
 };
+// Lock order: g_streams_mu is only ever taken for the map itself (look-up, insert, erase) and released before a state's `mu` is taken;
+// nothing takes g_streams_mu while holding a state's `mu`.  States are never destroyed: a dropped stream's state moves to g_retired,
+// so a reference another thread still holds (launch_sequence_mutex) stays valid whatever the caller does.
 std::mutex g_streams_mu;
-std::map<std::pair<int, hipStream_t>, StreamState> g_streams;       // node addresses are stable
+std::map<std::pair<int, hipStream_t>, std::shared_ptr<StreamState>> g_streams;
+std::vector<std::shared_ptr<StreamState>> g_retired;
+
+// the device a stream belongs to (NOT the calling thread's current device: sg_stream_destroy / sg_workspace_release may run after
+// the caller has moved on to another GPU); the null stream belongs to the current device
+int stream_device(hipStream_t s) {
+    int dev = 0;
+    if (s != nullptr && hipStreamGetDevice(s, &dev) == hipSuccess) return dev;
+    (void)hipGetLastError();
+    return hipGetDevice(&dev) == hipSuccess ? dev : -1;
+}
 
 StreamState* stream_state(hipStream_t s) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    const int dev = stream_device(s);
+    if (dev < 0) return nullptr;
     std::lock_guard<std::mutex> lock(g_streams_mu);
-    return &g_streams[{dev, s}];
+    auto& slot = g_streams[{dev, s}];
+    if (!slot) { slot = std::make_shared<StreamState>(); slot->device = dev; }
+    return slot.get();
+}
+
+// frees what a state holds, on the state's own device; the caller holds st.mu
+void free_state_memory(StreamState& st, bool sync_device) {
+    if (!st.ws && !st.scratch) return;
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    if (have_cur && cur != st.device) (void)hipSetDevice(st.device);
+    if (sync_device) (void)hipDeviceSynchronize();
+    if (st.ws) (void)hipFree(st.ws);
+    if (st.scratch) (void)hipFree(st.scratch);
+    if (have_cur && cur != st.device) (void)hipSetDevice(cur);
+    st.ws = nullptr;
+    st.ws_bytes = 0;
+    st.scratch = nullptr;
 }
 }  // namespace
 
@@ -397,35 +429,35 @@ void* stream_workspace(hipStream_t s, size_t bytes) {
     return st->ws;
 }
 
-// sg_stream_destroy: the stream's lock, reduction scratch and workspace go with it (the runtime may hand the same handle value to a
-// later stream; that one starts from an empty state).  The caller has synchronised the stream and no other thread is using it.
+// sg_stream_destroy: the stream's reduction scratch and workspace go with it and its state leaves the map (the runtime may hand the same
+// handle value to a later stream; that one starts from an empty state).  The caller has synchronised the stream.
 void drop_stream_state(hipStream_t s) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return;
-    std::lock_guard<std::mutex> lock(g_streams_mu);
-    auto it = g_streams.find({dev, s});
-    if (it == g_streams.end()) return;
-    if (it->second.scratch) (void)hipFree(it->second.scratch);
-    if (it->second.ws) (void)hipFree(it->second.ws);
-    g_streams.erase(it);
+    const int dev = stream_device(s);
+    std::shared_ptr<StreamState> st;
+    {
+        std::lock_guard<std::mutex> lock(g_streams_mu);
+        auto it = dev >= 0 ? g_streams.find({dev, s}) : g_streams.end();
+        if (it == g_streams.end()) {                         // (a stream whose device can no longer be asked: look for the handle on every device)
+            for (it = g_streams.begin(); it != g_streams.end() && it->first.second != s; ++it) {}
+            if (it == g_streams.end()) return;
+        }
+        st = it->second;
+        g_streams.erase(it);
+        g_retired.push_back(st);                             // ~100 bytes per destroyed stream, kept so that no reference to its lock dangles
+    }
+    std::lock_guard<std::recursive_mutex> l2(st->mu);
+    free_state_memory(*st, false);
 }
 
 extern "C" int sg_workspace_release(void) {
-    std::lock_guard<std::mutex> lock(g_streams_mu);
-    for (auto& kv : g_streams) {
-        std::lock_guard<std::recursive_mutex> l2(kv.second.mu);
-        if (kv.second.ws || kv.second.scratch) {             // (the reduction scratch comes back on its next use)
-            int cur = 0;
-            (void)hipGetDevice(&cur);
-            (void)hipSetDevice(kv.first.first);
-            (void)hipDeviceSynchronize();
-            if (kv.second.ws) (void)hipFree(kv.second.ws);
-            if (kv.second.scratch) (void)hipFree(kv.second.scratch);
-            (void)hipSetDevice(cur);
-            kv.second.ws = nullptr;
-            kv.second.ws_bytes = 0;
-            kv.second.scratch = nullptr;
-        }
+    std::vector<std::shared_ptr<StreamState>> all;
+    {
+        std::lock_guard<std::mutex> lock(g_streams_mu);
+        for (auto& kv : g_streams) all.push_back(kv.second);
+    }
+    for (auto& st : all) {                                   // one state at a time, g_streams_mu released: a launch sequence on another thread
+        std::lock_guard<std::recursive_mutex> l2(st->mu);    // holds its state's lock and may look the map up meanwhile without a deadlock
+        free_state_memory(*st, true);                        // (the reduction scratch comes back on its next use)
     }
     return SG_OK;
 }
@@ -655,7 +687,7 @@ int sg_band_totals(const void* spec_dev, int dtype, int64_t n_frames, int n_bins
     if (!parts) { set_error("band_totals: no scratch memory"); return SG_ERR_HIP; }
     // one round of resident workgroups (4 per CU at this kernel's register use), never more waves than row groups
     int cap = device_cu_count() * 4;
-    if (const char* e = getenv("SPECTRO_TOTALS_WG_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 8) cap = device_cu_count() * v; }   // tuning aid
+    if (const char* e = SG_TUNE_ENV("SPECTRO_TOTALS_WG_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 8) cap = device_cu_count() * v; }   // tuning aid
     if (cap > kMaxParts) cap = kMaxParts;
     const unsigned g = grid_for((n_frames + kRowsPerStep - 1) / kRowsPerStep * 64, cap);
     if (dtype == SG_F32)

@@ -19,6 +19,17 @@ int hip_fail(hipError_t e, const char* what);   // records message, returns SG_E
         if (e__ != hipSuccess) return ::sg::hip_fail(e__, #call);      \
     } while (0)
 
+// Tuning aids (SPECTRO_R8_OCC, SPECTRO_RBIG_NO_SLIDE ...: environment variables the A/B tools under tools/ flip between launches) exist only
+// in a -DSG_TUNING=1 build (`SG_TUNING=1 python build.py --force`, or tools/build_variant.sh <name> <file> -DSG_TUNING=1).  The product
+// library reads no environment variable on a launch path: getenv is not safe against a concurrent setenv, and the Python shim calls in
+// with the GIL released while another thread may be writing os.environ; a stray variable cannot change a release build's grid either.
+#ifdef SG_TUNING
+#include <cstdlib>
+#define SG_TUNE_ENV(name) getenv(name)
+#else
+#define SG_TUNE_ENV(name) (static_cast<const char*>(nullptr))
+#endif
+
 enum class Kernel { R8X3, R8X3D, RSMALL, RBIG, RBIGD, STOCKHAM, BLUESTEIN, RBLUE };
 
 }  // namespace sg

@@ -72,6 +72,7 @@ struct FusedParams {
     float scale;
     const float* wt;           // packed mel weights [16*NT][k_pad]
     int k_pad, n_mels, log_scale;
+    int form;                  // the caller's flags word (SG_MEL_FORM_*)
     int k_lo[kMaxTiles], k_hi[kMaxTiles];
     int debug;                 // ablation aid (SPECTRO_FUSED_DEBUG): 1 = consumers skip the MFMA loop, 2 = producers skip the FFT, 4 = no tile-row writes
 };
@@ -550,8 +551,7 @@ int launch_ws_one(const FusedParams& prm, int n_wg, hipStream_t s) {
 
 template <bool DETREND, int H>
 int launch_ws_nt(const FusedParams& prm, int nt, int n_wg, hipStream_t s) {
-    int cons = 8;
-    if (const char* e = getenv("SPECTRO_FUSED_CONS")) cons = atoi(e) == 4 ? 4 : 8;      // tuning aid
+    const int cons = (prm.form & SG_MEL_FORM_CONS4) ? 4 : 8;
     switch (nt) {
         case 1: return cons == 8 ? launch_ws_one<DETREND, 1, H, 8>(prm, n_wg, s) : launch_ws_one<DETREND, 1, H, 4>(prm, n_wg, s);
         case 2: return cons == 8 ? launch_ws_one<DETREND, 2, H, 8>(prm, n_wg, s) : launch_ws_one<DETREND, 2, H, 4>(prm, n_wg, s);
@@ -607,8 +607,7 @@ extern "C" int sg_stft_mel(const sg_plan* plan, const float* x_dev, int64_t n_sa
     prm.x = x_dev; prm.clip_stride = clip_stride; prm.n_frames = static_cast<int>(n_frames); prm.hop = plan->hop;
     prm.tiles_per_clip = static_cast<int>((n_frames + 15) / 16);
     prm.total_tiles = static_cast<int64_t>(prm.tiles_per_clip) * n_clips;
-    const char* ws = getenv("SPECTRO_FUSED_WS");
-    const bool use_v1 = !(ws && ws[0] == '1');                    // default kernel; SPECTRO_FUSED_WS=1 picks the wave-specialised form
+    const bool use_v1 = !(log_scale & SG_MEL_FORM_WS);            // default kernel; SG_MEL_FORM_WS picks the wave-specialised form
     int64_t n_wgs = static_cast<int64_t>(plan->n_cu) * (use_v1 ? 3 : 1);      // ws: 133-137 KiB of LDS = one workgroup per CU
     if (n_wgs > prm.total_tiles) n_wgs = prm.total_tiles;
     prm.n_wgs = static_cast<int>(n_wgs);
@@ -618,8 +617,8 @@ extern "C" int sg_stft_mel(const sg_plan* plan, const float* x_dev, int64_t n_sa
     prm.scale = static_cast<float>(plan->scale);
     prm.wt = packed_weights_dev;
     prm.k_pad = (plan->nfft / 2 + 1 + 15) & ~15;
-    prm.n_mels = n_mels; prm.log_scale = log_scale;
-    if (const char* e = getenv("SPECTRO_FUSED_DEBUG")) prm.debug = atoi(e);
+    prm.n_mels = n_mels; prm.log_scale = (log_scale & SG_MEL_LOG) != 0; prm.form = log_scale;
+    if (const char* e = SG_TUNE_ENV("SPECTRO_FUSED_DEBUG")) prm.debug = atoi(e);
     const int nt = (n_mels + 15) / 16;
     for (int t = 0; t < nt; ++t) {
         prm.k_lo[t] = tile_k_lo ? tile_k_lo[t] & ~15 : 0;

@@ -528,9 +528,9 @@ int r8x3_grid_waves(const sg_plan& p, int64_t total_frames, bool mel) {
     // short batches (the reference's own call: hop 896, 34 240 frames per 64 clips = 11 frames per wave at three waves per SIMD): two waves
     // per SIMD with runs half as long again are 2-5 % faster (32.3 vs 33.1-34.2 us, same box, two rounds; one wave: 42 us)
     if (occ > 2 && total_frames > static_cast<int64_t>(p.n_cu) * 4 * occ && total_frames < static_cast<int64_t>(p.n_cu) * 4 * occ * 14) occ = 2;
-    if (const char* e = getenv("SPECTRO_R8_OCC")) { const int v = atoi(e); if (v >= 1 && v <= kOccupancy) occ = v; }   // tuning aid
+    if (const char* e = SG_TUNE_ENV("SPECTRO_R8_OCC")) { const int v = atoi(e); if (v >= 1 && v <= kOccupancy) occ = v; }   // tuning aid
     int64_t n_waves = static_cast<int64_t>(p.n_cu) * 4 * occ;
-    if (const char* e = getenv("SPECTRO_R8_WAVES")) { const long v = atol(e); if (v >= 64 && v <= 65536) n_waves = v; }          // tuning aid
+    if (const char* e = SG_TUNE_ENV("SPECTRO_R8_WAVES")) { const long v = atol(e); if (v >= 64 && v <= 65536) n_waves = v; }          // tuning aid
     // GUI-sized calls (fewer frames than waves the chip holds): one frame per wave, latency before efficiency
     const int64_t by_work = total_frames <= n_waves ? total_frames : (total_frames + kMinRun - 1) / kMinRun;
     if (n_waves > by_work) n_waves = by_work;
@@ -560,7 +560,7 @@ int launch_r8x3(const sg_plan& p, const StftArgs& a) {
     prm.k_lo = a.k_lo;
     prm.k_hi = a.k_hi;
 #ifdef SG_R8_STAMP
-    if (const char* e = getenv("SPECTRO_R8_STAMP_PTR")) prm.stamps = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0));
+    if (const char* e = SG_TUNE_ENV("SPECTRO_R8_STAMP_PTR")) prm.stamps = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0));
 #endif
     int out = a.band_mode ? OUT_BAND : (p.mode == SG_MODE_PSD ? OUT_PSD : OUT_MAG);
     if (a.db_mode) {
@@ -586,9 +586,9 @@ int launch_r8x3(const sg_plan& p, const StftArgs& a) {
     const bool aligned = (p.hop % 2 == 0) && (a.clip_stride % 2 == 0) && (reinterpret_cast<uintptr_t>(a.x) % 8 == 0);
     // hops 64, 32, 16: two / four / eight interleaved hop-128 sequences, so the window slides in registers (one 8-byte load per
     // lane and frame instead of eight); rows of one sequence are 2 / 4 / 8 rows apart in the output
-    if (aligned && a.mel_ipl == 0 && (p.hop == 64 || p.hop == 32 || p.hop == 16) && !getenv("SPECTRO_R8_NO_SUB")) prm.sub = 128 / p.hop;
+    if (aligned && a.mel_ipl == 0 && (p.hop == 64 || p.hop == 32 || p.hop == 16) && !SG_TUNE_ENV("SPECTRO_R8_NO_SUB")) prm.sub = 128 / p.hop;
     // tuning aid (tools/ab_sub.py): walk ANY hop as `sub` interleaved sequences, e.g. hop 256 as two hop-512 sequences whose rows alternate in the output
-    if (const char* e = getenv("SPECTRO_R8_SUB")) { const int v = atoi(e); if (aligned && a.mel_ipl == 0 && v >= 1 && v <= 8) prm.sub = v; }
+    if (const char* e = SG_TUNE_ENV("SPECTRO_R8_SUB")) { const int v = atoi(e); if (aligned && a.mel_ipl == 0 && v >= 1 && v <= 8) prm.sub = v; }
     if (a.mel_ipl > 0 && !aligned) { set_error("r8x3: the mel form needs an even hop / clip stride and 8-byte aligned input"); return SG_ERR_UNSUPPORTED; }
     return launch_in<float>(prm, n_wg, a.stream, aligned, detrend, out);
 }

@@ -446,7 +446,7 @@ int launch_t(const sg_plan& p, const StftArgs& a) {
     prm.k_lo = a.k_lo; prm.k_hi = a.k_hi;
     // sliding window: hops 128 and 256 directly, hops 64 / 32 / 16 as 2 / 4 / 8 interleaved hop-128 sequences
     int h = 0;
-    const char* off = getenv("SPECTRO_RBIG_NO_SLIDE");      // A/B aid: "1" = never slide, "4" = not for T = 4
+    const char* off = SG_TUNE_ENV("SPECTRO_RBIG_NO_SLIDE");      // A/B aid: "1" = never slide, "4" = not for T = 4
     if (!(off && (off[0] == '1' || (off[0] == '4' && T == 4)))) {
         if (p.hop == 128 || p.hop == 256) h = p.hop / 128;
         else if (p.hop == 64 || p.hop == 32 || p.hop == 16) { h = 1; prm.sub = 128 / p.hop; }
@@ -456,7 +456,7 @@ int launch_t(const sg_plan& p, const StftArgs& a) {
     // behind) sliding lost by 4 % in round 2 (1.34 against 1.29 ms per 64-clip batch at hop 64); since the table reads went to
     // ds_read_b128 and the pass-2 twiddles to registers it wins: 1.185 / 0.611 / 0.320 against 1.277 / 0.651 / 0.335 ms at hops
     // 64 / 128 / 256 (profiles/r03_rbig_band_slide.txt).  SPECTRO_RBIG_BAND_RELOAD=1 restores the reloading form for an A/B.
-    if (T == 4 && band && getenv("SPECTRO_RBIG_BAND_RELOAD")) { h = 0; prm.sub = 1; }
+    if (T == 4 && band && SG_TUNE_ENV("SPECTRO_RBIG_BAND_RELOAD")) { h = 0; prm.sub = 1; }
     return p.detrend == SG_DETREND_CONSTANT ? launch_td<T, true>(prm, a.stream, p.mode, band, p.n_cu, h)
                                             : launch_td<T, false>(prm, a.stream, p.mode, band, p.n_cu, h);
 }

@@ -260,7 +260,7 @@ int launch_r(const sg_plan& p, const StftArgs& a) {
     prm.groups_per_clip = static_cast<int>((a.n_frames + G - 1) / G);
     prm.total_groups = static_cast<int64_t>(prm.groups_per_clip) * a.n_clips;
     int occ = 4;
-    if (const char* e = getenv("SPECTRO_RSMALL_OCC")) { const int v = atoi(e); if (v >= 1 && v <= 8) occ = v; }     // tuning aid
+    if (const char* e = SG_TUNE_ENV("SPECTRO_RSMALL_OCC")) { const int v = atoi(e); if (v >= 1 && v <= 8) occ = v; }     // tuning aid
     int64_t n_waves = static_cast<int64_t>(p.n_cu) * 4 * occ;
     const int64_t by_work = prm.total_groups <= n_waves ? prm.total_groups : (prm.total_groups + 1) / 2;     // small calls: a group per wave
     if (n_waves > by_work) n_waves = by_work;

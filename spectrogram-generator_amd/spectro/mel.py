@@ -127,9 +127,13 @@ class MelBank:
                                                        C.c_void_p(b_count.ptr), ipl, self.n_mels, int(bool(log_scale)),
                                                        C.c_void_p(out_ptr), int(out_clip_stride), C.c_void_p(stream)))
             return
+        # kernel form of the MFMA tile path: read from the environment HERE (under the GIL), handed over as flags -- the library reads none
+        flags = int(bool(log_scale))
+        if os.environ.get("SPECTRO_FUSED_WS") == "1":
+            flags |= 0x100 | (0x200 if os.environ.get("SPECTRO_FUSED_CONS") == "4" else 0)      # SG_MEL_FORM_WS | SG_MEL_FORM_CONS4
         _capi.check(_capi.lib().sg_stft_mel(plan.handle, C.c_void_p(x_ptr), int(n_samples), int(clip_stride), int(n_clips),
                                             C.c_void_p(self._dev.ptr), self.n_bins, self.n_mels, self._k_lo, self._k_hi,
-                                            int(bool(log_scale)), C.c_void_p(out_ptr), int(out_clip_stride), C.c_void_p(stream)))
+                                            flags, C.c_void_p(out_ptr), int(out_clip_stride), C.c_void_p(stream)))
 
     def close(self):
         self._dev.free()
