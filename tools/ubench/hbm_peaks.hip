@@ -194,6 +194,76 @@ void sweep(const char* name, const T* a, T* b, size_t bytes_in, double bytes_mov
     fflush(stdout);
 }
 
+
+// Round 4: the traffic shape of a workgroup-staged headline kernel, memory + LDS only.  A workgroup of 4 waves owns one
+// contiguous run of rows (frames); per step it takes 4 consecutive rows 4j + i (wave i): the 4 * 256 new samples of the step arrive as ONE
+// coalesced 16-byte load per lane (256 lanes x 16 B), go into an LDS ring (ds_write_b128), one LDS-only workgroup barrier, then every wave
+// reads its frame from the ring (8 ds_read_b64 per lane: z[lane + 64 a], as the register layout wants it) and stores its row with the nine
+// dword stores of the product kernel -- so the workgroup writes 4 adjacent rows (8 208 contiguous bytes) and the chip sees a quarter of the
+// write fronts of the wave-per-run layout.  The next step's samples are requested before this step's rows are stored.  No arithmetic.
+// RING: 4096 samples (16 KiB) per workgroup, so the step j + 1 stores never land on what step j still reads (one barrier per step).
+template <int OCC>
+__global__ __launch_bounds__(256, OCC) void rows_wg_k(const float* __restrict__ x, float* __restrict__ out, long n_rows, int n_wg) {
+    __shared__ __attribute__((aligned(16))) float ring[4096];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (blockIdx.x >= n_wg) return;
+    const long g0 = (n_rows / 4 * blockIdx.x / n_wg) * 4, g1 = blockIdx.x + 1 == n_wg ? n_rows & ~3L : (n_rows / 4 * (blockIdx.x + 1) / n_wg) * 4;
+    if (g0 >= g1) return;
+    // prologue: the first 1792 samples of the run (7 x 256) -- two 16-byte loads per lane cover 2048
+    const float* src = x + g0 * 256;
+    {
+        const v4f a = *reinterpret_cast<const v4f*>(src + 4 * threadIdx.x);
+        const v4f b = *reinterpret_cast<const v4f*>(src + 1024 + 4 * threadIdx.x);
+        *reinterpret_cast<v4f*>(ring + 4 * threadIdx.x) = a;
+        *reinterpret_cast<v4f*>(ring + 1024 + 4 * threadIdx.x) = b;
+    }
+    long pos = 2048;                                         // samples of the run staged so far
+    v4f nxt = *reinterpret_cast<const v4f*>(src + pos + 4 * threadIdx.x);
+    for (long f = g0; f < g1; f += 4) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_barrier();                        // the step's samples are in the ring
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // this wave's frame: samples (f - g0 + wave) * 256 ... + 1024 of the run, ring index modulo 4096
+        const int base = static_cast<int>(((f - g0 + wave) * 256) & 4095);
+        float s = 0.f;
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            typedef float v2f_ __attribute__((ext_vector_type(2)));
+            const v2f_ v = *reinterpret_cast<const volatile v2f_*>(ring + ((base + 2 * lane + 128 * a) & 4095));
+            s += v.x + v.y;
+        }
+        // the samples the NEXT step needs beyond what is staged: 1024 more; store the ones already fetched, request the following ones
+        *reinterpret_cast<v4f*>(ring + ((pos + 4 * threadIdx.x) & 4095)) = nxt;
+        pos += 1024;
+        {
+            const long want = pos + 4 * threadIdx.x;
+            const long lim = (g1 - g0) * 256 + 768 - 4;      // last sample of the run's last frame
+            nxt = *reinterpret_cast<const v4f*>(src + (want < lim ? want : lim));
+        }
+        float* row = out + (f + wave) * 513;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { row[lane + 64 * m] = s; row[512 - lane - 64 * m] = s; }
+        row[256] = s;
+    }
+}
+
+template <int OCC>
+void rows_wg(const float* x, float* out) {
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const long n_rows = 119808L * 8;
+    const int n_wg = 256 * OCC;                              // OCC workgroups of 4 waves per CU = OCC waves per SIMD
+    hipLaunchKernelGGL((rows_wg_k<OCC>), dim3(n_wg), dim3(256), 0, 0, x, out, n_rows, n_wg);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    const int reps = 4;
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((rows_wg_k<OCC>), dim3(n_wg), dim3(256), 0, 0, x, out, n_rows, n_wg);
+    CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    printf("stft rows, workgroup-staged (4 waves, LDS ring, 4 adjacent rows per step)   occ %d waves/SIMD: %.2f TB/s  (%.1f us per 119808 rows)\n", OCC,
+           (double)n_rows * 3076 * reps / (ms * 1e-3) / 1e12, ms * 1e3 / reps / 8);
+    fflush(stdout);
+}
+
 template <int SHAPE>
 void rows(const char* name, const float* x, float* out, int occ) {
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -245,6 +315,15 @@ int main(int argc, char** argv) {
         CHECK(hipMemset(a1, 0, (size_t)2 << 30));
         for (int rep = 0; rep < 2; ++rep)
             for (int occ : {2, 3, 4}) { rows_deep<1>(a1, b1, occ); rows_deep<2>(a1, b1, occ); rows_deep<3>(a1, b1, occ); }
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "wgstage")) {       // ./hbm_peaks.bin wgstage: the workgroup-staged row model against the wave-per-run one
+        for (int rep = 0; rep < 2; ++rep) {
+            rows<0>("stft rows (wave per run, product)", a1, b1, 2);
+            rows<0>("stft rows (wave per run, product)", a1, b1, 3);
+            rows<0>("stft rows (wave per run, product)", a1, b1, 4);
+            rows_wg<2>(a1, b1); rows_wg<3>(a1, b1); rows_wg<4>(a1, b1);
+        }
         return 0;
     }
     const bool rows_only = argc > 1 && !strcmp(argv[1], "rows");     // ./hbm_peaks.bin rows: only the STFT row-pattern models
