@@ -7,7 +7,7 @@
 // The real frame of n samples is packed into N2 = n/2 complex points z[m] = x[2m] + i x[2m+1] (as every register kernel here does);
 // its N2-point DFT -- N2 is not a power of two -- is a chirp-z transform on the REGISTER FFT machinery of stft_rbig.hip:
 //     Z[k] = c[k] * sum_m (z[m] c[m]) * b[k - m],     c[m] = exp(-i pi m^2 / N2),  b[j] = exp(+i pi j^2 / N2)
-// the convolution being circular of length L = 1024 (T = 2: N2 <= 512) or 2048 (T = 4: N2 <= 1024), L >= 2 N2 - 1:
+// the convolution being circular of length L = 512 (T = 1: N2 <= 256), 1024 (T = 2: N2 <= 512) or 2048 (T = 4: N2 <= 1024), L >= 2 N2 - 1:
 //     A = FFT_L(z c)  ->  Y = conj(A * B), B = FFT_L(b) / L (host, double)  ->  V = FFT_L(Y)  ->  Z[k] = c[k] * conj(V[k]),  k < N2
 // (an inverse transform is the forward one between two conjugations; the forward transform leaves Z[lane + 64 c] in register c of
 // the lane, which is exactly the input layout, so the second transform starts from the registers of the first: no exchange between
@@ -32,11 +32,11 @@ __device__ __forceinline__ v4f lds_get2(const float2* p) { return *(__attribute_
 
 template <int T> struct BlueCfg {
     static constexpr int R = 8 * T, M = 64 * R;                          // L = M complex points
-    static constexpr int kOcc = T == 2 ? 4 : 2;                          // waves per SIMD
+    static constexpr int kOcc = T == 4 ? 2 : 4;                          // waves per SIMD
     static constexpr int kWaves = 8;                                     // per workgroup (T = 2: two workgroups per CU)
     static constexpr int kRowsIn = R / 2;                                // rows (of 64 complex) a frame can fill: N2 <= M / 2
     static constexpr int kRowsOut = R / 2 + 1;                           // rows of output bins k = 0..N2
-    static constexpr int kSlab = T == 2 ? 8 * kS1 : 2 * 8 * kS1;         // float2 per wave: one exchange group, and N2 + 1 split entries
+    static constexpr int kSlab = T == 4 ? 2 * 8 * kS1 : 8 * kS1;         // float2 per wave: one exchange group, and N2 + 1 split entries
     // LDS tables, in float2 units
     static constexpr int kWc = 0;                                        // [kRowsIn][64] float4 (w[2m], w[2m+1], cos, -sin of the chirp)
     static constexpr int kFilt = kWc + 2 * kRowsIn * 64;                 // [R/2][64][2]: rows 2m, 2m+1 of a lane side by side
@@ -64,6 +64,7 @@ struct BlueParams {
 };
 
 template <int T> __device__ __forceinline__ void radix_t(float2 (&v)[T]);
+template <> __device__ __forceinline__ void radix_t<1>(float2 (&)[1]) {}
 template <> __device__ __forceinline__ void radix_t<2>(float2 (&v)[2]) {
     const float2 s = cadd(v[0], v[1]), d = csub(v[0], v[1]);
     v[0] = s; v[1] = d;
@@ -78,7 +79,7 @@ template <> __device__ __forceinline__ void radix_t<4>(float2 (&v)[4]) {
 // exp(-2*pi*i*n/R), R = 16 / 32: compile-time indices after unrolling
 template <int R> __device__ __forceinline__ float2 const_tw(int n) {
     constexpr float kPi = 3.14159265358979323846f;
-    const int m = n & (R - 1);
+    const int m = n & (R - 1);                               // (R = 8: never called with a0 > 0)
     // (cosf / sinf of a constant fold at compile time)
     return make_float2(__builtin_cosf(-2.0f * kPi * m / R), __builtin_sinf(-2.0f * kPi * m / R));
 }
@@ -372,7 +373,7 @@ int upload(void** dev, const std::vector<V>& host) {
 
 }  // namespace
 
-int rblue_size(int nfft) { return nfft <= 1024 ? 2 : 4; }     // T of a plan rblue_ok() accepts
+int rblue_size(int nfft) { return nfft <= 512 ? 1 : nfft <= 1024 ? 2 : 4; }     // T of a plan rblue_ok() accepts
 
 bool rblue_can_run(const sg_plan& p, const StftArgs& a) {
     return !a.in_i16 && (p.hop % 2 == 0) && (a.clip_stride % 2 == 0 || a.n_clips == 1) &&
@@ -381,7 +382,8 @@ bool rblue_can_run(const sg_plan& p, const StftArgs& a) {
 
 int launch_rblue(const sg_plan& p, const StftArgs& a) {
     if (a.n_frames <= 0 || a.n_clips <= 0) return SG_OK;
-    return rblue_size(p.nfft) == 2 ? launch_t<2>(p, a) : launch_t<4>(p, a);
+    const int T = rblue_size(p.nfft);
+    return T == 1 ? launch_t<1>(p, a) : T == 2 ? launch_t<2>(p, a) : launch_t<4>(p, a);
 }
 
 // Tables of the register chirp-z kernel (computed in double): window pairs + input/output chirp, filter spectrum, split twiddles,
