@@ -158,6 +158,16 @@ static int run_converted(const sg_plan* plan, StftArgs& a) {
     return rc;
 }
 
+// A chirp-z plan's LDS kernel: its tables are built the first time a call needs them (the register kernel takes practically every call).
+static int launch_bluestein_lazy(const sg_plan* plan, const StftArgs& a) {
+    static std::mutex mu;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!plan->bs_chirp_dev) { if (int rc = build_bluestein_tables(*const_cast<sg_plan*>(plan))) return rc; }
+    }
+    return launch_bluestein(*plan, a);
+}
+
 // The fused band power of a chirp-z plan on a call its register kernel cannot take (odd hop, unaligned clips): full spectra by the LDS
 // kernel into a block of their own, then the band sums.  A rare path (the register kernel serves every even hop): the block is a plain
 // hipMalloc / hipFree pair -- the stream's workspace may be holding the float copy of an int16 call around this one.
@@ -169,7 +179,7 @@ static int band_via_spectrum(const sg_plan* plan, StftArgs& a) {
     f.band_mode = 0;
     f.out = spec;
     f.out_clip_stride = a.n_frames * nbins;
-    int rc = launch_bluestein(*plan, f);
+    int rc = launch_bluestein_lazy(plan, f);
     for (int c = 0; rc == SG_OK && c < a.n_clips; ++c)
         rc = sg_band_sum(static_cast<const float*>(spec) + static_cast<int64_t>(c) * a.n_frames * nbins, SG_F32, a.n_frames, nbins, a.k_lo, a.k_hi,
                          static_cast<float*>(a.out) + static_cast<int64_t>(c) * a.out_clip_stride, a.stream);
@@ -205,7 +215,8 @@ static int run_stft(const sg_plan* plan, StftArgs& a) {
         case Kernel::STOCKHAM: return launch_stockham(*plan, a);
         case Kernel::BLUESTEIN: return launch_bluestein(*plan, a);
         // odd hops / unaligned clips, GUI-sized int16 calls: the LDS chirp-z kernel (its tables are built with the plan); it writes full spectra only
-        case Kernel::RBLUE: return rblue_can_run(*plan, a) ? launch_rblue(*plan, a) : a.band_mode ? band_via_spectrum(plan, a) : launch_bluestein(*plan, a);
+        // (more than 2^31 frames per clip: the LDS chirp-z kernel, whose tables this plan builds on first need)
+        case Kernel::RBLUE: return rblue_can_run(*plan, a) ? launch_rblue(*plan, a) : a.band_mode ? band_via_spectrum(plan, a) : launch_bluestein_lazy(plan, a);
     }
     return SG_ERR_UNSUPPORTED;
 }
@@ -365,8 +376,7 @@ int sg_plan_create(sg_plan** plan, int nperseg, int nfft, int hop, const double*
             p->kernel = Kernel::STOCKHAM;
         } else if (rblue_ok(*p)) {
             p->kernel = Kernel::RBLUE;
-            rc = build_rblue_tables(*p, w);
-            if (rc == SG_OK) rc = build_bluestein_tables(*p);     // the fallback of calls the register kernel cannot take
+            rc = build_rblue_tables(*p, w);                   // (the LDS kernel's tables are built on first need: launch_bluestein_lazy)
         } else {
             p->kernel = Kernel::BLUESTEIN;
             rc = build_bluestein_tables(*p);

@@ -55,6 +55,8 @@ struct BlueParams {
     float* out;
     int64_t out_clip_stride;
     int n2;                    // nperseg / 2
+    int aligned;               // every frame starts on an 8-byte boundary (even hop, even clip stride, aligned base): one 8-byte load per point;
+                               // else two 4-byte loads (the reference's own call at nperseg 1000 has hop 875, PlotEngine.py:113)
     const v4f* wc;             // [kRowsIn * 64]
     const float2* filt;        // [M]   FFT_M(b) / M, natural order
     const float2* stw;         // [kRowsOut * 64]  exp(-2 pi i k / n), k <= n2 (zero beyond)
@@ -195,9 +197,15 @@ __global__ __launch_bounds__((64 * BlueCfg<T>::kWaves), (BlueCfg<T>::kOcc)) void
 
     auto load_frame = [&](int clip, int f, float2 (&dst)[C::kRowsIn]) {
         const float* const src = p.x + static_cast<int64_t>(clip) * p.clip_stride + static_cast<int64_t>(f) * p.hop + 2 * lane;
+        if (p.aligned) {                                     // wave-uniform
 #pragma unroll
-        for (int a = 0; a < C::kRowsIn; ++a)
-            dst[a] = lane + 64 * a < n2 ? *reinterpret_cast<const float2*>(src + 128 * a) : make_float2(0.f, 0.f);
+            for (int a = 0; a < C::kRowsIn; ++a)
+                dst[a] = lane + 64 * a < n2 ? *reinterpret_cast<const float2*>(src + 128 * a) : make_float2(0.f, 0.f);
+        } else {
+#pragma unroll
+            for (int a = 0; a < C::kRowsIn; ++a)
+                dst[a] = lane + 64 * a < n2 ? make_float2(src[128 * a], src[128 * a + 1]) : make_float2(0.f, 0.f);
+        }
     };
 
     int clip = static_cast<int>(g / p.n_frames);
@@ -329,6 +337,7 @@ int launch_t(const sg_plan& p, const StftArgs& a) {
     prm.out = static_cast<float*>(a.out);
     prm.out_clip_stride = a.out_clip_stride;
     prm.n2 = p.nfft / 2;
+    prm.aligned = (p.hop % 2 == 0) && (a.clip_stride % 2 == 0 || a.n_clips == 1) && (reinterpret_cast<uintptr_t>(a.x) % 8 == 0);
     prm.wc = static_cast<const v4f*>(p.rb_wc_dev);
     prm.filt = static_cast<const float2*>(p.rb_filt_dev);
     prm.stw = static_cast<const float2*>(p.rb_stw_dev);
@@ -375,9 +384,9 @@ int upload(void** dev, const std::vector<V>& host) {
 
 int rblue_size(int nfft) { return nfft <= 512 ? 1 : nfft <= 1024 ? 2 : 4; }     // T of a plan rblue_ok() accepts
 
-bool rblue_can_run(const sg_plan& p, const StftArgs& a) {
-    return !a.in_i16 && (p.hop % 2 == 0) && (a.clip_stride % 2 == 0 || a.n_clips == 1) &&
-           (reinterpret_cast<uintptr_t>(a.x) % 8 == 0) && a.n_frames <= INT32_MAX;
+// (odd hops and clips at odd strides run here too, with 4-byte loads; int16 input is converted first, spectro_api.hip)
+bool rblue_can_run(const sg_plan&, const StftArgs& a) {
+    return !a.in_i16 && (reinterpret_cast<uintptr_t>(a.x) % 4 == 0) && a.n_frames <= INT32_MAX;
 }
 
 int launch_rblue(const sg_plan& p, const StftArgs& a) {

@@ -955,8 +955,8 @@ def test_rblue_kernel(sp, n, hop, detrend, mode, window):
 @pytest.mark.parametrize("n,hop", [(1000, 250), (96, 32), (1504, 188)])
 def test_rblue_band_power_int16_and_fallbacks(sp, n, hop):
     """The register chirp-z kernel's other entry points: fused band power (A11) == the sum over the written bins; int16 batches
-    (converted once on the device); calls it cannot take -- odd hop, clips at an odd stride -- run the LDS kernel, spectra and band
-    power alike, with the same values."""
+    (converted once on the device); odd hops and clips at an odd stride (the reference's own call at nperseg 1000 has hop 875) take
+    4-byte loads in the same kernel, spectra and band power alike, with the same values."""
     from spectro import _capi
     from spectro.signal import plan_for
     from spectro.windows import get_window
@@ -986,7 +986,7 @@ def test_rblue_band_power_int16_and_fallbacks(sp, n, hop):
     _, _, s_i = sp.spectrogram(xi, fs=48000.0, nperseg=n, window="hann", noverlap=n - hop)
     _, _, s_f = sp.spectrogram(xi.astype(np.float32), fs=48000.0, nperseg=n, window="hann", noverlap=n - hop)
     np.testing.assert_array_equal(s_i, s_f)
-    # odd hop, and clips at an odd stride (ns - 1 samples of each row): the LDS kernel takes the call
+    # odd hop, and clips at an odd stride (ns - 1 samples of each row): the unaligned loads of the same kernel
     for kw, xs in ((dict(noverlap=n - hop - 1), x), (dict(noverlap=n - hop), x[:, :ns - 1] if (ns - 1) % 2 else x[:, :ns - 2])):
         _, _, s1 = sp.spectrogram(xs, fs=48000.0, nperseg=n, window="hann", **kw)
         _, _, so = orc.spectrogram(xs, fs=48000.0, nperseg=n, window="hann", **kw)
