@@ -590,6 +590,20 @@ def time_secondary(_capi, get_window, xs, dev, stream):
     plan.close()
     del xb, ob
 
+    # ---- the reference's non-power-of-two nperseg (GUI.py:87-89): nperseg 1000, hop 250 and the reference's own hop 875, register chirp-z kernel
+    np2 = {}
+    for hop_np2 in (250, 875):
+        pn = _capi.Plan(1000, 1000, hop_np2, get_window("hann" if hop_np2 == 250 else ("tukey", 0.25), 1000), _capi.DETREND["constant"], FS,
+                        _capi.SCALING["density"], _capi.MODE["psd"], _capi.F32)
+        nf = pn.n_frames(N_SAMPLES)
+        o2 = [torch.empty((n_clips, nf, 501), device=dev, dtype=torch.float32) for _ in range(2)]
+        us = timed(lambda i: pn.stft(xs[i % len(xs)].data_ptr(), N_SAMPLES, N_SAMPLES, n_clips, o2[i % 2].data_ptr(), nf * 501, stream=stream), 24, settle_s=0.05, budget_s=0.0)
+        np2[f"hop_{hop_np2}"] = {"kernel": pn.kernel, "frames": n_clips * nf, "us": us, "frames_per_s": n_clips * nf / us * 1e6,
+                                 "bytes_per_frame": hop_np2 * 4 + 501 * 4, "frac_of_hbm_peak": n_clips * nf * (hop_np2 * 4 + 501 * 4) / us / 1e3 / HBM_PEAK_GBS}
+        pn.close()
+        del o2
+    out["nperseg_1000"] = np2
+
     # ---- cfg5: streaming 8 ch x 96 kHz, n_fft 4096 hop 1024, 4096-sample chunks, synchronous feed() host to host (PCIe inclusive)
     st = StreamingSTFT(8, 96000.0, 4096, 1024, window="hann")
     chunk = (np.random.default_rng(5).standard_normal((8, 4096)) * 0.1).astype(np.float32)

@@ -394,3 +394,27 @@ def test_bench_barrier_and_reduce_through_rccl_with_one_rank():
     assert d["gather"]["band_power"]["values_ok"] is True and d["gather"]["band_power"]["collective"] == "all_gather_into_tensor"
     assert d["gather"]["full_spectra"]["shapes_ok"] is True
     assert abs(d["roofline"]["frac"] - d["value"] * 3076 / 8e12) < 1e-9
+
+
+def test_bench_line_carries_the_secondary_configs():
+    """the driver-run bench line reports BASELINE's other configs and the >= 4 GB batch as untimed `secondary` legs,
+    and the graded fields are what they were: one clock for value / ms_per_step / roofline.frac, cfg2 as the workload."""
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SPECTRO_BENCH_SAME_GPU"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--telemetry-s", "0", "--no-cpu-baseline",
+                        "--no-reference-mode", "--no-limiter-leg"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["unit"] == "frames/s" and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert abs(d["roofline"]["frac"] - d["value"] * 3076 / 8e12) < 1e-9 and d["config"]["frames_per_step_per_gpu"] == 119808
+    s = d["secondary"]
+    assert set(s) >= {"cfg3_fused_mel", "cfg4_sweep_64clips", "cfg5_streaming", "large_batch", "nperseg_1000"}
+    assert s["cfg3_fused_mel"]["bytes_per_frame"] == 1344 and s["cfg3_fused_mel"]["frames"] == 119808 and 30 < s["cfg3_fused_mel"]["us"] < 400
+    c4 = s["cfg4_sweep_64clips"]
+    assert len(c4["per_pair"]) == 15 and {(p["n_fft"], p["hop"]) for p in c4["per_pair"]} == {(n, h) for n in (256, 512, 1024, 2048, 4096) for h in (64, 128, 256)}
+    assert abs(c4["total_ms"] - sum(p["us"] for p in c4["per_pair"]) / 1e3) < 1e-9 and c4["shared_hops_ms"] < c4["total_ms"] and c4["band_power_ms"] < c4["total_ms"]
+    assert {p["kernel"] for p in c4["per_pair"]} == {"rsmall", "r8x3", "rbig"}
+    assert s["large_batch"]["clips"] == 768 and s["large_batch"]["GB"] > 4.0 and 0.3 < s["large_batch"]["frac"] < 0.8
+    assert s["cfg5_streaming"]["realtime_factor"] > 50 and s["cfg5_streaming"]["chunk_ms_p50"] <= s["cfg5_streaming"]["chunk_ms_p99"]
+    assert s["nperseg_1000"]["hop_250"]["kernel"] == "rblue" and s["nperseg_1000"]["hop_875"]["kernel"] == "rblue"
