@@ -796,7 +796,7 @@ def test_random_shapes_property(sp):
             p = plan_for(get_window(window, n_eff), n_eff, n_eff, hop, _capi.DETREND[detrend], kw["fs"], 0, 0,
                          _capi.F32 if dt == np.float32 else _capi.F64)
             families.add(p.kernel)
-    assert {"r8x3", "rsmall", "rbig", "stockham", "bluestein"} <= families, families
+    assert {"r8x3", "rsmall", "rbig", "rblue", "stockham", "bluestein"} <= families, families
 
 
 def test_abi_argument_errors(sp):
