@@ -26,7 +26,7 @@ def test_abi_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in spectro.h but not exported"
     assert declared == set(_capi.SIGNATURES), declared ^ set(_capi.SIGNATURES)
-    assert lib.sg_version() == 102
+    assert lib.sg_version() == 103
 
 
 def test_host_shim_under_address_and_ub_sanitizers():
