@@ -50,6 +50,34 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, unsigned long lo
                 asm volatile("v_cndmask_b32 %0, %1, %0, vcc\n v_cndmask_b32 %2, %3, %2, vcc\n v_cndmask_b32 %4, %5, %4, vcc\n v_cndmask_b32 %6, %7, %6, vcc\n"
                              "v_cndmask_b32 %1, %2, %1, vcc\n v_cndmask_b32 %3, %4, %3, vcc\n v_cndmask_b32 %5, %6, %5, vcc\n v_cndmask_b32 %7, %0, %7, vcc\n"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : : "vcc");
+            } else if (KIND == 8) {   // v_fmamk_f32: literal constant K (what `fmaf(h, x, y)` with a float literal compiles to)
+                asm volatile("v_fmamk_f32 %0, %0, 0x3f3504f3, %8\n v_fmamk_f32 %1, %1, 0x3f3504f3, %8\n v_fmamk_f32 %2, %2, 0x3f3504f3, %8\n v_fmamk_f32 %3, %3, 0x3f3504f3, %8\n"
+                             "v_fmamk_f32 %4, %4, 0x3f3504f3, %8\n v_fmamk_f32 %5, %5, 0x3f3504f3, %8\n v_fmamk_f32 %6, %6, 0x3f3504f3, %8\n v_fmamk_f32 %7, %7, 0x3f3504f3, %8\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c));
+            } else if (KIND == 9) {   // v_mul_f32 with a literal
+                asm volatile("v_mul_f32 %0, 0x3f3504f3, %0\n v_mul_f32 %1, 0x3f3504f3, %1\n v_mul_f32 %2, 0x3f3504f3, %2\n v_mul_f32 %3, 0x3f3504f3, %3\n"
+                             "v_mul_f32 %4, 0x3f3504f3, %4\n v_mul_f32 %5, 0x3f3504f3, %5\n v_mul_f32 %6, 0x3f3504f3, %6\n v_mul_f32 %7, 0x3f3504f3, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            } else if (KIND == 10) {  // v_mul_f32 with an SGPR source
+                asm volatile("v_mul_f32 %0, %8, %0\n v_mul_f32 %1, %8, %1\n v_mul_f32 %2, %8, %2\n v_mul_f32 %3, %8, %3\n"
+                             "v_mul_f32 %4, %8, %4\n v_mul_f32 %5, %8, %5\n v_mul_f32 %6, %8, %6\n v_mul_f32 %7, %8, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "s"(b));
+            } else if (KIND == 11) {  // v_mul_f32 with an inline constant (0.5)
+                asm volatile("v_mul_f32 %0, 0.5, %0\n v_mul_f32 %1, 0.5, %1\n v_mul_f32 %2, 0.5, %2\n v_mul_f32 %3, 0.5, %3\n"
+                             "v_mul_f32 %4, 0.5, %4\n v_mul_f32 %5, 0.5, %5\n v_mul_f32 %6, 0.5, %6\n v_mul_f32 %7, 0.5, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            } else if (KIND == 12) {  // v_mul_f32 with a VGPR constant
+                asm volatile("v_mul_f32 %0, %8, %0\n v_mul_f32 %1, %8, %1\n v_mul_f32 %2, %8, %2\n v_mul_f32 %3, %8, %3\n"
+                             "v_mul_f32 %4, %8, %4\n v_mul_f32 %5, %8, %5\n v_mul_f32 %6, %8, %6\n v_mul_f32 %7, %8, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+            } else if (KIND == 13) {  // v_fma_f32 (VOP3) with an SGPR multiplier
+                asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                             "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "s"(b), "v"(c));
+            } else if (KIND == 14) {  // v_pk_add_f32
+                asm volatile("v_pk_add_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %4\n v_pk_add_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %4\n"
+                             "v_pk_add_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %4\n v_pk_add_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %4\n"
+                             : "+v"(*reinterpret_cast<double*>(&a0)), "+v"(*reinterpret_cast<double*>(&a2)), "+v"(*reinterpret_cast<double*>(&a4)), "+v"(*reinterpret_cast<double*>(&a6)) : "v"(*reinterpret_cast<const double*>(&b)));
             } else if (KIND == 7) {   // v_mov_b32 plain
                 asm volatile("v_mov_b32 %0, %1\n v_mov_b32 %2, %3\n v_mov_b32 %4, %5\n v_mov_b32 %6, %7\n v_mov_b32 %1, %2\n v_mov_b32 %3, %4\n v_mov_b32 %5, %6\n v_mov_b32 %7, %0\n"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
@@ -91,5 +119,11 @@ int main() {
     run<5>("v_mov_b32_dpp row_ror:8 bank_mask", out);
     run<6>("v_cndmask_b32", out);
     run<7>("v_mov_b32", out);
+    run<8>("v_fmamk_f32 (literal K)", out);
+    run<9>("v_mul_f32 literal", out);
+    run<10>("v_mul_f32 SGPR source", out);
+    run<11>("v_mul_f32 inline constant 0.5", out);
+    run<12>("v_mul_f32 VGPR constant", out);
+    run<13>("v_fma_f32 SGPR multiplier", out);
     return 0;
 }
