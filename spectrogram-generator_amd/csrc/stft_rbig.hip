@@ -45,6 +45,16 @@ __device__ __forceinline__ v4f lds_get2(const float2* p) { return *(__attribute_
 #define SG_RBIG_B128 1             // window, t1 and t3 tables keep rows 2m, 2m+1 of a lane side by side: one ds_read_b128 per two rows (a b128 read moves twice
                                    // the bytes in 1.3x the time); -1 ... -2.7 % on every shape (profiles/r03_rbig_b128_tables.txt); 0 = one ds_read_b64 per row
 #endif
+#ifndef SG_RBIG_SADDR
+#define SG_RBIG_SADDR 1            // the row pointer is made wave-uniform (v_readfirstlane of its offset) so that the 8T + 1 stores of a row take the
+                                   // `global_store_dword v_offset, v_data, s[base:base+1] offset:imm` form: one address VGPR per store instead of a 64-bit
+                                   // pair and no 64-bit VALU address arithmetic (timing what-ifs: the row stores are 27 % of the nfft-4096 launch)
+#endif
+__device__ __forceinline__ int64_t uniform_i64(int64_t v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v));
+    const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(static_cast<uint64_t>(v) >> 32));
+    return static_cast<int64_t>((static_cast<uint64_t>(hi) << 32) | lo);
+}
 #ifndef SG_RBIG4_OCC
 #define SG_RBIG4_OCC 3            // waves per SIMD the T = 4 kernel is compiled for
 #endif
@@ -149,7 +159,12 @@ __global__ __launch_bounds__((64 * WavesFor<T, H>::value), (OccFor<T, H>::value)
     }
 
     // one frame: samples d[][] (destroyed) -> row orow
-    auto frame = [&](float2 (&d)[T][8], float* const orow) {
+    auto frame = [&](float2 (&d)[T][8], float* const orow_in) {
+#if SG_RBIG_SADDR
+        float* const orow = p.out + uniform_i64(orow_in - p.out);          // (an offset: the pointer keeps its global address space)
+#else
+        float* const orow = orow_in;
+#endif
         float bsum = 0.f;                                    // MODE 2: this lane's share of the band sum (A11)
         if (DETREND) {
             float s = d[0][0].x + d[0][0].y;

@@ -264,6 +264,53 @@ void rows_wg(const float* x, float* out) {
     fflush(stdout);
 }
 
+// Round 4: the product's row shape with the row pointer made wave-uniform (v_readfirstlane of both halves), so that the nine stores take the
+// `global_store_dword v_offset, v_data, s[base:base+1] offset:imm` form (one address VGPR instead of a 64-bit pair, no 64-bit VALU adds) and the
+// loads likewise.  Same traffic as rows_k<0>.
+__device__ __forceinline__ long uniform_long(long v) {       // (an element offset, so that the pointer keeps its global address space)
+    const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v)), hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(static_cast<unsigned long long>(v) >> 32));
+    return static_cast<long>((static_cast<unsigned long long>(hi) << 32) | lo);
+}
+__global__ __launch_bounds__(256) void rows_saddr_k(const float* __restrict__ x, float* __restrict__ out, long n_rows, int n_waves) {
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (w >= n_waves) return;
+    const long g0 = n_rows * w / n_waves, g1 = n_rows * (w + 1) / n_waves;
+    long xo = uniform_long(g0 * 256), ro = uniform_long(g0 * 513);
+    float2 v = *reinterpret_cast<const float2*>(x + xo + 2 * lane);
+    float2 u = *reinterpret_cast<const float2*>(x + xo + 128 + 2 * lane);
+    const int up = lane, dn = 512 - lane;                    // the two per-lane offsets (floats)
+    for (long f = g0; f < g1; ++f) {
+        const float s = v.x + v.y + u.x + u.y;
+        xo = uniform_long(xo + 256);
+        if (f + 1 < g1) {
+            v = *reinterpret_cast<const float2*>(x + xo + 2 * lane);
+            u = *reinterpret_cast<const float2*>(x + xo + 128 + 2 * lane);
+        }
+        float* const row = out + ro;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { row[up + 64 * m] = s; row[dn - 64 * m] = s; }
+        row[256] = s;
+        ro = uniform_long(ro + 513);
+    }
+}
+
+void rows_saddr(const float* x, float* out, int occ) {
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const long n_rows = 119808L * 8;
+    const int n_waves = 256 * 4 * occ, grid = n_waves / 4;
+    hipLaunchKernelGGL(rows_saddr_k, dim3(grid), dim3(256), 0, 0, x, out, n_rows, n_waves);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    const int reps = 4;
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(rows_saddr_k, dim3(grid), dim3(256), 0, 0, x, out, n_rows, n_waves);
+    CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    printf("stft rows, SGPR base + VGPR offset stores    occ %d waves/SIMD: %.2f TB/s  (%.1f us per 119808 rows)\n", occ,
+           (double)n_rows * 3076 * reps / (ms * 1e-3) / 1e12, ms * 1e3 / reps / 8);
+    fflush(stdout);
+}
+
 template <int SHAPE>
 void rows(const char* name, const float* x, float* out, int occ) {
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -324,6 +371,11 @@ int main(int argc, char** argv) {
             rows<0>("stft rows (wave per run, product)", a1, b1, 4);
             rows_wg<2>(a1, b1); rows_wg<3>(a1, b1); rows_wg<4>(a1, b1);
         }
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "saddr")) {         // ./hbm_peaks.bin saddr: the product's rows with 64-bit VGPR addresses against SGPR base + VGPR offset
+        for (int rep = 0; rep < 2; ++rep)
+            for (int occ : {2, 3, 4}) { rows<0>("stft rows (64-bit VGPR addresses)", a1, b1, occ); rows_saddr(a1, b1, occ); }
         return 0;
     }
     const bool rows_only = argc > 1 && !strcmp(argv[1], "rows");     // ./hbm_peaks.bin rows: only the STFT row-pattern models
