@@ -28,6 +28,13 @@ namespace {
 
 using namespace wavefft;
 
+#ifndef SG_RSMALL_X4
+#define SG_RSMALL_X4 1          // the staged rows of a group leave as 16-byte stores (ds_read_b128 from the slab, global_store_dwordx4): a quarter of the store
+                                // instructions: -1 ... -4 % (profiles/r04_rsmall_whatif.txt).  Round 4's what-ifs: this kernel's time is its global loads and stores (removing
+                                // either saves 30-35 %), not its exchanges or arithmetic (removing any of them changes nothing); a second group of prefetch and a round-robin deal
+                                // of the groups do not help (+4 %, +-2 %): it runs at 3.5-3.7 TB/s of a 1 : 2 read : write mix from 4 096 streams.
+                                // (the rows start on 4-byte boundaries: the 16-byte stores are unaligned, which the hardware takes.)  0 = dword stores
+#endif
 #ifndef SG_RSMALL_WPW
 #define SG_RSMALL_WPW 4
 #endif
@@ -228,11 +235,26 @@ __global__ __launch_bounds__(64 * kWaves) void stft_rsmall_kernel(const SmallPar
             wave_lds_fence();
             const int n_live = min(G, p.n_frames - fg) * NB;            // (wave-uniform; a partial last group writes fewer rows)
             float* const obase = p.out + static_cast<int64_t>(clip) * p.out_clip_stride + static_cast<int64_t>(fg) * NB;
+#if SG_RSMALL_X4
+            typedef float v4f_ __attribute__((ext_vector_type(4)));
+            typedef v4f_ v4f_u __attribute__((aligned(4)));
+#pragma unroll
+            for (int i = 0; i < (G * NB + 255) / 256; ++i) {           // 4 floats per lane and instruction; the last quad of the live rows may be partial
+                const int idx = 4 * (lane + 64 * i);
+                if (idx + 3 < n_live) {
+                    *reinterpret_cast<v4f_u*>(obase + idx) = *(const __attribute__((address_space(3))) volatile v4f_*)(stage + idx);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) if (idx + e < n_live) obase[idx + e] = stage[idx + e];
+                }
+            }
+#else
 #pragma unroll
             for (int i = 0; i < (G * NB + 63) / 64; ++i) {
                 const int idx = lane + 64 * i;
                 if (idx < n_live) obase[idx] = stage[idx];
             }
+#endif
         }
         wave_lds_fence();
         clip = clip_n;
