@@ -127,7 +127,7 @@ int sg_plan_n_bins(const sg_plan* plan, int* n_bins);
 /* the scale factor the kernels multiply |X|^2 with (as double) */
 int sg_plan_scale(const sg_plan* plan, double* scale);
 /* name of the kernel family the plan dispatches to: "r8x3", "r8x3d" / "rsmalld" (f64 nperseg = nfft = 1024 / 256, 512), "rsmall", "rbig", "rbigd",
- * "rblue" (f32, even nperseg = nfft <= 2048 that is no power of two: register chirp-z), "stockham", "bluestein" */
+ * "rblue" / "rblued" (f32 / f64, even nperseg = nfft <= 2048 / 1024 that is no power of two: register chirp-z), "stockham", "bluestein" */
 const char* sg_plan_kernel(const sg_plan* plan);
 /* Tests / benchmarks: route the plan to another family that can run it ("stockham" for an
  * r8x3 plan).  SG_ERR_UNSUPPORTED if that family cannot run this plan. */

@@ -55,6 +55,13 @@ static bool rblue_ok(const sg_plan& p) {
            (p.mode == SG_MODE_PSD || p.mode == SG_MODE_MAGNITUDE);
 }
 
+// ... and in double precision up to 1024 (stft_rblue_f64.hip): the reference's recordings are float64
+static bool rblued_ok(const sg_plan& p) {
+    return p.dtype == SG_F64 && p.nperseg == p.nfft && p.nfft % 2 == 0 && !is_pow2(p.nfft) && p.nfft >= 6 && p.nfft <= 1024 &&
+           (p.detrend == SG_DETREND_NONE || p.detrend == SG_DETREND_CONSTANT) &&
+           (p.mode == SG_MODE_PSD || p.mode == SG_MODE_MAGNITUDE);
+}
+
 static bool stockham_ok(const sg_plan& p) {
     if (!is_pow2(p.nfft) || p.nfft < 2) return false;
     // LDS need of the largest case: one frame per workgroup, two nfft-real buffers + reduction scratch
@@ -216,6 +223,10 @@ static int run_stft(const sg_plan* plan, StftArgs& a) {
         case Kernel::BLUESTEIN: return launch_bluestein(*plan, a);
         // odd hops / unaligned clips, GUI-sized int16 calls: the LDS chirp-z kernel (its tables are built with the plan); it writes full spectra only
         // (more than 2^31 frames per clip: the LDS chirp-z kernel, whose tables this plan builds on first need)
+        case Kernel::RBLUED:
+            if (rblue_f64_can_run(*plan, a)) return launch_rblue_f64(*plan, a);
+            if (a.band_mode) { set_error("band power of this chirp-z plan needs 8-byte aligned float64 input"); return SG_ERR_UNSUPPORTED; }
+            return launch_bluestein_lazy(plan, a);
         case Kernel::RBLUE: return rblue_can_run(*plan, a) ? launch_rblue(*plan, a) : a.band_mode ? band_via_spectrum(plan, a) : launch_bluestein_lazy(plan, a);
     }
     return SG_ERR_UNSUPPORTED;
@@ -374,6 +385,9 @@ int sg_plan_create(sg_plan** plan, int nperseg, int nfft, int hop, const double*
             rc = build_rbig_f64_tables(*p);
         } else if (stockham_ok(*p)) {
             p->kernel = Kernel::STOCKHAM;
+        } else if (rblued_ok(*p)) {
+            p->kernel = Kernel::RBLUED;
+            rc = build_rblue_f64_tables(*p, w);
         } else if (rblue_ok(*p)) {
             p->kernel = Kernel::RBLUE;
             rc = build_rblue_tables(*p, w);                   // (the LDS kernel's tables are built on first need: launch_bluestein_lazy)
@@ -423,6 +437,7 @@ const char* sg_plan_kernel(const sg_plan* plan) {
         case Kernel::STOCKHAM: return "stockham";
         case Kernel::BLUESTEIN: return "bluestein";
         case Kernel::RBLUE: return "rblue";
+        case Kernel::RBLUED: return "rblued";
     }
     return "";
 }
@@ -462,6 +477,11 @@ int sg_plan_force_kernel(sg_plan* plan, const char* name) {
     if (!strcmp(name, "stockham")) {
         if (!stockham_ok(*plan)) { set_error("plan cannot run on stockham"); return SG_ERR_UNSUPPORTED; }
         plan->kernel = Kernel::STOCKHAM;
+        return SG_OK;
+    }
+    if (!strcmp(name, "rblued")) {
+        if (!rblued_ok(*plan) || !plan->rb_wc_dev) { set_error("plan cannot run on rblued"); return SG_ERR_UNSUPPORTED; }
+        plan->kernel = Kernel::RBLUED;
         return SG_OK;
     }
     if (!strcmp(name, "rblue")) {

@@ -74,6 +74,7 @@ CASES = [  # dtype, nperseg, hop, window, forced family, expected family
     ("f32", 1000, 250, "hann", None, "rblue"),
     ("f32", 1000, 250, "hann", "bluestein", "bluestein"),
     ("f64", 1024, 256, ("tukey", 0.25), None, "r8x3d"),
+    ("f64", 1000, 250, "hann", None, "rblued"),
 ]
 
 

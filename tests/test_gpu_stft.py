@@ -1004,3 +1004,57 @@ def test_rblue_band_power_int16_and_fallbacks(sp, n, hop):
     assert np.all(np.abs(got - ref) <= 1e-4 * np.abs(ref) + 1e-12)
     for b in (d_in, d_s, d_bp, d2):
         b.free()
+
+
+@pytest.mark.parametrize("n,hop,detrend,mode,window", [
+    (1000, 250, "constant", "psd", "hann"), (1000, 875, "constant", "psd", ("tukey", 0.25)), (960, 240, False, "magnitude", "hann"),
+    (96, 24, "constant", "psd", ("tukey", 0.25)), (480, 419, "constant", "psd", "hann"), (6, 2, "constant", "psd", "boxcar"),
+    (34, 30, False, "psd", "hann"), (1022, 2, "constant", "magnitude", "hann"), (514, 128, "constant", "psd", "boxcar")])
+def test_rblue_f64_kernel(sp, n, hop, detrend, mode, window):
+    """The reference's own flow at a non-power-of-two nperseg: float64 recordings (SweepManager.py:135-136) and the spin box's 32-steps
+    (GUI.py:87-89).  The double-precision register chirp-z kernel (stft_rblue_f64.hip, round 4) against the oracle at f64 tolerance, against the
+    LDS kernel of the same plan, the fused band power, an odd hop (the reference's literal hop at nperseg 1000 is 875) and clips at an odd stride."""
+    from spectro import _capi
+    from spectro.signal import plan_for
+    from spectro.windows import get_window
+    rng = np.random.default_rng(n * 3 + hop)
+    N = n + hop * 23 + 6
+    x = rng.standard_normal((5, N)) * 0.4 + 0.2
+    x[2] = 0.0
+    x[3] = -7.5
+    kw = dict(fs=48000.0, nperseg=n, window=window, noverlap=n - hop, detrend=detrend, mode=mode)
+    plan = plan_for(get_window(window, n), n, n, hop, _capi.DETREND[detrend], 48000.0, 0, _capi.MODE[mode], _capi.F64)
+    assert plan.kernel == "rblued"
+    f, t, s = sp.spectrogram(x, **kw)
+    fo, to, so = orc.spectrogram(x, **kw)
+    np.testing.assert_array_equal(f, fo)
+    np.testing.assert_array_equal(t, to)
+    keep = [0, 1, 4] if detrend else [0, 1, 3, 4]
+    _check(s[keep], so[keep], np.float64)
+    assert np.all(s[2] == 0.0)
+    if detrend:
+        assert np.abs(s[3]).max() <= 1e-20 * max(np.abs(s[0]).max(), 1e-300) + 1e-28
+    plan.force_kernel("bluestein")
+    try:
+        _, _, s_lds = sp.spectrogram(x, **kw)
+    finally:
+        plan.force_kernel("rblued")
+    _check(s[keep], s_lds[keep], np.float64)
+    # clips at an odd stride (N - 1 samples of each row of the same buffer): 8-byte loads
+    xs = x[:, :N - 1] if (N - 1) % 2 else x[:, :N - 2]
+    _, _, s1 = sp.spectrogram(xs, **kw)
+    _, _, so1 = orc.spectrogram(xs, **kw)
+    _check(s1[keep], so1[keep], np.float64)
+    if mode == "psd":                                        # fused band power == the sum over the written bins
+        nfr, nb = plan.n_frames(N), n // 2 + 1
+        d_in, d_bp = _capi.DeviceBuffer(x.nbytes), _capi.DeviceBuffer(5 * nfr * 8)
+        d_in.upload(np.ascontiguousarray(x))
+        h = n // 2
+        for k_lo, k_hi in [(0, h), (1, min(7, h)), (h, h), (h // 2, h - 1)]:
+            plan.band_power(d_in.ptr, N, N, 5, k_lo, k_hi, d_bp.ptr, nfr)
+            bp = np.empty((5, nfr), np.float64)
+            d_bp.download(bp)
+            _capi.stream_sync()
+            ref = np.moveaxis(s, -1, -2)[:, :, k_lo:k_hi + 1].sum(-1)
+            assert np.all(np.abs(bp - ref) <= 1e-12 * np.moveaxis(s, -1, -2).sum(-1) + 1e-300), (k_lo, k_hi)
+        d_in.free(); d_bp.free()

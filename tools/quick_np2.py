@@ -7,16 +7,20 @@ from spectro import _capi
 from spectro.windows import get_window
 _capi.ensure_device()
 N, n_clips = 480000, 64
-x = (np.random.default_rng(1).standard_normal((n_clips, N)) * 0.1).astype(np.float32)
+f64 = os.environ.get("QN_DTYPE", "f32") == "f64"          # QN_DTYPE=f64: the double-precision kernel (nperseg <= 1024)
+dt, code, isz = (np.float64, _capi.F64, 8) if f64 else (np.float32, _capi.F32, 4)
+x = (np.random.default_rng(1).standard_normal((n_clips, N)) * 0.1).astype(dt)
 ins = [_capi.DeviceBuffer(x.nbytes) for _ in range(4)]
 for b in ins: b.upload(x)
 secs = float(os.environ.get("QB_SECS", "0.5"))
 shapes = [(1000, 250), (960, 240), (96, 24), (480, 120), (1504, 376), (2016, 504), (1000, 876)]
+if f64:
+    shapes = [(1000, 250), (960, 240), (96, 24), (480, 120), (1000, 875)]
 for n, hop in shapes:
-    plan = _capi.Plan(n, n, hop, get_window("hann", n), 1, 48000.0, 0, 0, _capi.F32)
+    plan = _capi.Plan(n, n, hop, get_window("hann", n), 1, 48000.0, 0, 0, code)
     nf = plan.n_frames(N)
-    outs = [_capi.DeviceBuffer(n_clips * nf * (n // 2 + 1) * 4) for _ in range(2)]
-    d_bp = _capi.DeviceBuffer(n_clips * nf * 4)
+    outs = [_capi.DeviceBuffer(n_clips * nf * (n // 2 + 1) * isz) for _ in range(2)]
+    d_bp = _capi.DeviceBuffer(n_clips * nf * isz)
     res = {}
     for kern in (plan.kernel, "bluestein"):
         plan.force_kernel(kern)
@@ -33,7 +37,7 @@ for n, hop in shapes:
             res[(kern, name)] = (time.perf_counter() - t0) / k
     fr = n_clips * nf
     k0 = [k for k in res if k[0] != "bluestein" and k[1] == "spectrum"][0]
-    bpf = hop * 4 + (n // 2 + 1) * 4
+    bpf = hop * isz + (n // 2 + 1) * isz
     print(f"n{n} hop {hop}: {k0[0]} {res[k0]*1e6:8.1f} us ({fr/res[k0]/1e6:7.1f} M frames/s, {fr*bpf/res[k0]/1e12:.2f} TB/s algorithmic)  band {res.get((k0[0], 'band'), 0)*1e6:8.1f} us"
           f"   | LDS chirp-z {res[('bluestein', 'spectrum')]*1e6:9.1f} us ({fr/res[('bluestein', 'spectrum')]/1e6:6.1f} M frames/s)  -> x{res[('bluestein', 'spectrum')]/res[k0]:.1f}", flush=True)
     for o in outs: o.free()
