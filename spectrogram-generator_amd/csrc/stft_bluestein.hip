@@ -4,7 +4,7 @@
 //
 // Chirp-z (Bluestein):  with b[j] = exp(+i*pi*j^2/n)
 //     X[k] = conj(b[k]) * sum_m (y[m]*conj(b[m])) * b[k-m]
-// i.e. one circular convolution of length L = 2^q >= 2n-1 done with two in-place radix-2 FFTs in LDS:
+// i.e. one circular convolution of length L = 2^q >= 2n-1 done with two in-place radix-2 FFTs in LDS (round 4: two stages per pass):
 //     forward DIF (natural in, bit-reversed out)  ->  * H (filter spectrum stored bit-reversed, 1/L folded in)
 //     -> inverse DIT (bit-reversed in, natural out).  No bit-reversal pass, a single L-point complex buffer.
 // One 256-thread workgroup owns one frame at a time.  Framing / detrend / window / epilogue are the same
@@ -106,19 +106,42 @@ __global__ __launch_bounds__(kThreads) void stft_bluestein_kernel(const BsParams
         }
         __syncthreads();
 
-        // ---- forward DIF ----
-        for (int st = 0; st < p.log2L; ++st) {
-            const int half = halfL >> st;
-            for (int i = tid; i < halfL; i += kThreads) {
-                const int r = i & (half - 1);
-                const int j = ((i - r) << 1) + r;
-                const Cx<T> u = C[j], v = C[j + half];
-                const Cx<T> w = p.tw[static_cast<size_t>(r) << st];
-                const T dx = u.x - v.x, dy = u.y - v.y;
-                C[j] = {u.x + v.x, u.y + v.y};
-                C[j + half] = {dx * w.x - dy * w.y, dx * w.y + dy * w.x};
+        // ---- forward DIF: two radix-2 stages per pass (round 4: half the workgroup barriers; the data order after a fused pass is that of the two
+        //      single passes, so the bit-reversed filter table is unchanged); one single stage closes an odd log2 L ----
+        {
+            int st = 0;
+            for (; st + 1 < p.log2L; st += 2) {
+                const int q = L >> (st + 2);
+                for (int i = tid; i < (L >> 2); i += kThreads) {
+                    const int r = i & (q - 1);
+                    const int j = ((i - r) << 2) + r;
+                    const Cx<T> x0 = C[j], x1 = C[j + q], x2 = C[j + 2 * q], x3 = C[j + 3 * q];
+                    const Cx<T> wa0 = p.tw[static_cast<size_t>(r) << st], wa1 = p.tw[static_cast<size_t>(r + q) << st], wb = p.tw[static_cast<size_t>(r) << (st + 1)];
+                    const Cx<T> y0 = {x0.x + x2.x, x0.y + x2.y}, d02 = {x0.x - x2.x, x0.y - x2.y};
+                    const Cx<T> y1 = {x1.x + x3.x, x1.y + x3.y}, d13 = {x1.x - x3.x, x1.y - x3.y};
+                    const Cx<T> y2 = {d02.x * wa0.x - d02.y * wa0.y, d02.x * wa0.y + d02.y * wa0.x};
+                    const Cx<T> y3 = {d13.x * wa1.x - d13.y * wa1.y, d13.x * wa1.y + d13.y * wa1.x};
+                    const Cx<T> e01 = {y0.x - y1.x, y0.y - y1.y}, e23 = {y2.x - y3.x, y2.y - y3.y};
+                    C[j] = {y0.x + y1.x, y0.y + y1.y};
+                    C[j + q] = {e01.x * wb.x - e01.y * wb.y, e01.x * wb.y + e01.y * wb.x};
+                    C[j + 2 * q] = {y2.x + y3.x, y2.y + y3.y};
+                    C[j + 3 * q] = {e23.x * wb.x - e23.y * wb.y, e23.x * wb.y + e23.y * wb.x};
+                }
+                __syncthreads();
             }
-            __syncthreads();
+            for (; st < p.log2L; ++st) {
+                const int half = halfL >> st;
+                for (int i = tid; i < halfL; i += kThreads) {
+                    const int r = i & (half - 1);
+                    const int j = ((i - r) << 1) + r;
+                    const Cx<T> u = C[j], v = C[j + half];
+                    const Cx<T> w = p.tw[static_cast<size_t>(r) << st];
+                    const T dx = u.x - v.x, dy = u.y - v.y;
+                    C[j] = {u.x + v.x, u.y + v.y};
+                    C[j + half] = {dx * w.x - dy * w.y, dx * w.y + dy * w.x};
+                }
+                __syncthreads();
+            }
         }
         // ---- pointwise multiply with the filter spectrum (both bit-reversed) ----
         for (int i = tid; i < L; i += kThreads) {
@@ -126,19 +149,44 @@ __global__ __launch_bounds__(kThreads) void stft_bluestein_kernel(const BsParams
             C[i] = {a.x * h.x - a.y * h.y, a.x * h.y + a.y * h.x};
         }
         __syncthreads();
-        // ---- inverse DIT ----
-        for (int st = p.log2L - 1; st >= 0; --st) {
-            const int half = halfL >> st;
-            for (int i = tid; i < halfL; i += kThreads) {
-                const int r = i & (half - 1);
-                const int j = ((i - r) << 1) + r;
-                const Cx<T> w = p.tw[static_cast<size_t>(r) << st];       // conj applied below
-                const Cx<T> u = C[j], t = C[j + half];
-                const Cx<T> v = {t.x * w.x + t.y * w.y, t.y * w.x - t.x * w.y};
-                C[j] = {u.x + v.x, u.y + v.y};
-                C[j + half] = {u.x - v.x, u.y - v.y};
+        // ---- inverse DIT: the mirror image -- a single stage first when log2 L is odd, then two stages per pass ----
+        {
+            int st = p.log2L - 1;
+            if (p.log2L & 1) {
+                const int half = halfL >> st;
+                for (int i = tid; i < halfL; i += kThreads) {
+                    const int r = i & (half - 1);
+                    const int j = ((i - r) << 1) + r;
+                    const Cx<T> w = p.tw[static_cast<size_t>(r) << st];       // conj applied below
+                    const Cx<T> u = C[j], t = C[j + half];
+                    const Cx<T> v = {t.x * w.x + t.y * w.y, t.y * w.x - t.x * w.y};
+                    C[j] = {u.x + v.x, u.y + v.y};
+                    C[j + half] = {u.x - v.x, u.y - v.y};
+                }
+                __syncthreads();
+                --st;
             }
-            __syncthreads();
+            for (; st >= 1; st -= 2) {                       // stages st (half q) then st - 1 (half 2q)
+                const int q = halfL >> st;
+                const int s0 = st - 1;
+                for (int i = tid; i < (L >> 2); i += kThreads) {
+                    const int r = i & (q - 1);
+                    const int j = ((i - r) << 2) + r;
+                    const Cx<T> x0 = C[j], x1 = C[j + q], x2 = C[j + 2 * q], x3 = C[j + 3 * q];
+                    const Cx<T> wb = p.tw[static_cast<size_t>(r) << st], wa0 = p.tw[static_cast<size_t>(r) << s0], wa1 = p.tw[static_cast<size_t>(r + q) << s0];
+                    const Cx<T> v1 = {x1.x * wb.x + x1.y * wb.y, x1.y * wb.x - x1.x * wb.y};      // x * conj(w)
+                    const Cx<T> v3 = {x3.x * wb.x + x3.y * wb.y, x3.y * wb.x - x3.x * wb.y};
+                    const Cx<T> a0 = {x0.x + v1.x, x0.y + v1.y}, a1 = {x0.x - v1.x, x0.y - v1.y};
+                    const Cx<T> a2 = {x2.x + v3.x, x2.y + v3.y}, a3 = {x2.x - v3.x, x2.y - v3.y};
+                    const Cx<T> u2 = {a2.x * wa0.x + a2.y * wa0.y, a2.y * wa0.x - a2.x * wa0.y};
+                    const Cx<T> u3 = {a3.x * wa1.x + a3.y * wa1.y, a3.y * wa1.x - a3.x * wa1.y};
+                    C[j] = {a0.x + u2.x, a0.y + u2.y};
+                    C[j + 2 * q] = {a0.x - u2.x, a0.y - u2.y};
+                    C[j + q] = {a1.x + u3.x, a1.y + u3.y};
+                    C[j + 3 * q] = {a1.x - u3.x, a1.y - u3.y};
+                }
+                __syncthreads();
+            }
         }
 
         // ---- post-chirp + epilogue ----
