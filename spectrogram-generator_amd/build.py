@@ -18,7 +18,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libspectro.so")
-SOURCES = ["host_shim.cpp", "spectro_api.hip", "stft_r8x3.hip", "stft_r8x3_f64.hip", "stft_rsmall.hip", "stft_rbig.hip", "stft_rbig_f64.hip", "stft_stockham.hip", "stft_bluestein.hip", "stft_rblue.hip", "stft_rblue_f64.hip", "epilogue.hip", "mel.hip", "stft_mel_fused.hip"]
+SOURCES = ["host_shim.cpp", "spectro_api.hip", "stft_r8x3.hip", "stft_r8x3_f64.hip", "stft_rsmall.hip", "stft_rbig.hip", "stft_rbig_f64.hip", "stft_stockham.hip", "stft_bluestein.hip", "stft_rblue.hip", "stft_rblue_f64.hip", "stft_rbluew.hip", "epilogue.hip", "mel.hip", "stft_mel_fused.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-fno-gpu-rdc",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 if os.environ.get("SG_TUNING") == "1":          # the launch-time tuning variables of the A/B tools (csrc/spectro_internal.h: SG_TUNE_ENV); never in the product build
@@ -28,7 +28,7 @@ if os.environ.get("SG_TUNING") == "1":          # the launch-time tuning variabl
 # register-pair shuffles (v_pk_mov/v_mov) -- keep the scalar forms.
 EXTRA = {"mel.hip": os.environ.get("SG_MEL_DEFS", "").split(),
          "stft_r8x3.hip": (["-fno-slp-vectorize"] if not os.environ.get("SG_SLP") else []) + os.environ.get("SG_R8_DEFS", "").split(),
-         "stft_rsmall.hip": ["-fno-slp-vectorize"] + os.environ.get("SG_RSMALL_DEFS", "").split(), "stft_rbig.hip": ["-fno-slp-vectorize"] + os.environ.get("SG_RBIG_DEFS", "").split(), "stft_rblue.hip": ["-fno-slp-vectorize"] + os.environ.get("SG_RBLUE_DEFS", "").split(), "stft_mel_fused.hip": ["-fno-slp-vectorize"] + os.environ.get("SG_FUSED_DEFS", "").split()}
+         "stft_rsmall.hip": ["-fno-slp-vectorize"] + os.environ.get("SG_RSMALL_DEFS", "").split(), "stft_rbig.hip": ["-fno-slp-vectorize"] + os.environ.get("SG_RBIG_DEFS", "").split(), "stft_rblue.hip": ["-fno-slp-vectorize"] + os.environ.get("SG_RBLUE_DEFS", "").split(), "stft_rbluew.hip": ["-fno-slp-vectorize"] + os.environ.get("SG_RBLUEW_DEFS", "").split(), "stft_mel_fused.hip": ["-fno-slp-vectorize"] + os.environ.get("SG_FUSED_DEFS", "").split()}
 
 
 def hipcc():

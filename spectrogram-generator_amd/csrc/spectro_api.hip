@@ -62,6 +62,14 @@ static bool rblued_ok(const sg_plan& p) {
            (p.mode == SG_MODE_PSD || p.mode == SG_MODE_MAGNITUDE);
 }
 
+// ... and from 2048 to 8192 with two / four wavefronts per frame (stft_rbluew.hip): nperseg a multiple of 4 / 8
+static bool rbluew_ok(const sg_plan& p) {
+    return p.dtype == SG_F32 && p.nperseg == p.nfft && !is_pow2(p.nfft) && p.nfft > 2048 && p.nfft <= 8192 &&
+           p.nfft % (2 * rbluew_size(p.nfft)) == 0 &&
+           (p.detrend == SG_DETREND_NONE || p.detrend == SG_DETREND_CONSTANT) &&
+           (p.mode == SG_MODE_PSD || p.mode == SG_MODE_MAGNITUDE);
+}
+
 static bool stockham_ok(const sg_plan& p) {
     if (!is_pow2(p.nfft) || p.nfft < 2) return false;
     // LDS need of the largest case: one frame per workgroup, two nfft-real buffers + reduction scratch
@@ -212,7 +220,7 @@ static int run_stft(const sg_plan* plan, StftArgs& a) {
     if (a.in_i16 && (plan->kernel == Kernel::RSMALL || plan->kernel == Kernel::RBIG) && plan->hop % 2 == 0 &&
         (a.clip_stride % 2 == 0 || a.n_clips == 1) && static_cast<int64_t>(a.n_clips) * a.n_samples >= (1 << 18))
         return run_converted(plan, a);
-    if (plan->kernel == Kernel::RBLUE && a.in_i16) return run_converted(plan, a);     // neither chirp-z kernel loads int16
+    if ((plan->kernel == Kernel::RBLUE || plan->kernel == Kernel::RBLUEW) && a.in_i16) return run_converted(plan, a);     // no chirp-z kernel loads int16
     switch (plan->kernel) {
         case Kernel::R8X3: return launch_r8x3(*plan, a);
         case Kernel::R8X3D: return r8x3_f64_can_run(*plan, a) ? launch_r8x3_f64(*plan, a) : launch_stockham(*plan, a);
@@ -228,6 +236,7 @@ static int run_stft(const sg_plan* plan, StftArgs& a) {
             if (a.band_mode) { set_error("band power of this chirp-z plan needs 8-byte aligned float64 input"); return SG_ERR_UNSUPPORTED; }
             return launch_bluestein_lazy(plan, a);
         case Kernel::RBLUE: return rblue_can_run(*plan, a) ? launch_rblue(*plan, a) : a.band_mode ? band_via_spectrum(plan, a) : launch_bluestein_lazy(plan, a);
+        case Kernel::RBLUEW: return rbluew_can_run(*plan, a) ? launch_rbluew(*plan, a) : a.band_mode ? band_via_spectrum(plan, a) : launch_bluestein_lazy(plan, a);
     }
     return SG_ERR_UNSUPPORTED;
 }
@@ -391,6 +400,9 @@ int sg_plan_create(sg_plan** plan, int nperseg, int nfft, int hop, const double*
         } else if (rblue_ok(*p)) {
             p->kernel = Kernel::RBLUE;
             rc = build_rblue_tables(*p, w);                   // (the LDS kernel's tables are built on first need: launch_bluestein_lazy)
+        } else if (rbluew_ok(*p)) {
+            p->kernel = Kernel::RBLUEW;
+            rc = build_rbluew_tables(*p, w);
         } else {
             p->kernel = Kernel::BLUESTEIN;
             rc = build_bluestein_tables(*p);
@@ -438,6 +450,7 @@ const char* sg_plan_kernel(const sg_plan* plan) {
         case Kernel::BLUESTEIN: return "bluestein";
         case Kernel::RBLUE: return "rblue";
         case Kernel::RBLUED: return "rblued";
+        case Kernel::RBLUEW: return "rbluew";
     }
     return "";
 }
@@ -488,6 +501,12 @@ int sg_plan_force_kernel(sg_plan* plan, const char* name) {
         if (!rblue_ok(*plan)) { set_error("plan cannot run on rblue"); return SG_ERR_UNSUPPORTED; }
         if (!plan->rb_wc_dev) { set_error("rblue tables are built with the plan only"); return SG_ERR_UNSUPPORTED; }
         plan->kernel = Kernel::RBLUE;
+        return SG_OK;
+    }
+    if (!strcmp(name, "rbluew")) {
+        if (!rbluew_ok(*plan)) { set_error("plan cannot run on rbluew"); return SG_ERR_UNSUPPORTED; }
+        if (!plan->rb_wc_dev) { set_error("rbluew tables are built with the plan only"); return SG_ERR_UNSUPPORTED; }
+        plan->kernel = Kernel::RBLUEW;
         return SG_OK;
     }
     if (!strcmp(name, "bluestein")) {

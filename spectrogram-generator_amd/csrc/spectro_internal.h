@@ -30,7 +30,7 @@ int hip_fail(hipError_t e, const char* what);   // records message, returns SG_E
 #define SG_TUNE_ENV(name) (static_cast<const char*>(nullptr))
 #endif
 
-enum class Kernel { R8X3, R8X3D, RSMALL, RBIG, RBIGD, STOCKHAM, BLUESTEIN, RBLUE, RBLUED };
+enum class Kernel { R8X3, R8X3D, RSMALL, RBIG, RBIGD, STOCKHAM, BLUESTEIN, RBLUE, RBLUED, RBLUEW };
 
 }  // namespace sg
 
@@ -54,7 +54,7 @@ struct sg_plan {
     void* bs_filter_dev = nullptr;  // FFT_L of conj-chirp filter, bit-reversed order, pre-scaled by 1/L
     void* bs_tw_dev = nullptr;      // exp(-2*pi*i*k/L), k < L/2
     // register chirp-z tables (RBLUE, stft_rblue.hip): window pairs + chirp, filter spectrum, split twiddles, per-lane FFT twiddles
-    void* rb_wc_dev = nullptr;      // (RBLUED, stft_rblue_f64.hip: ONE table of (re, im) double pairs holds all of them)
+    void* rb_wc_dev = nullptr;      // (RBLUED, stft_rblue_f64.hip: ONE table of (re, im) double pairs holds all of them; RBLUEW, stft_rbluew.hip: one float2 table)
     void* rb_filt_dev = nullptr;
     void* rb_stw_dev = nullptr;
     void* rb_tw_dev = nullptr;
@@ -101,6 +101,9 @@ int launch_bluestein(const sg_plan& p, const StftArgs& a);
 int launch_rblue(const sg_plan& p, const StftArgs& a);
 bool rblue_can_run(const sg_plan& p, const StftArgs& a);
 int launch_rblue_f64(const sg_plan& p, const StftArgs& a);
+int launch_rbluew(const sg_plan& p, const StftArgs& a);
+bool rbluew_can_run(const sg_plan& p, const StftArgs& a);
+int rbluew_size(int nfft);
 bool rblue_f64_can_run(const sg_plan& p, const StftArgs& a);
 
 int build_r8x3_tables(sg_plan& p, const std::vector<double>& window);
@@ -111,5 +114,7 @@ int build_rbig_f64_tables(sg_plan& p);
 int build_bluestein_tables(sg_plan& p);
 int build_rblue_tables(sg_plan& p, const std::vector<double>& window);
 int build_rblue_f64_tables(sg_plan& p, const std::vector<double>& window);
+int build_rbluew_tables(sg_plan& p, const std::vector<double>& window);
+void host_fft_pow2(std::vector<double>& re, std::vector<double>& im);     // in place, forward, radix 2 (stft_rblue.hip)
 
 }  // namespace sg

@@ -16,7 +16,7 @@
 // One wavefront = one frame, no workgroup barrier in the frame loop; detrend / window / PSD scale as in stft_rbig.hip (the PSD scale
 // rides on the window table).  Index maps of the transform: tools/sim_rbig.py.  Algorithmic HBM bytes per frame: hop*4 + (n/2+1)*4.
 #include "spectro_internal.h"
-#include "fft_wave.h"
+#include "cfft_wave.h"
 
 #include <cmath>
 #include <vector>
@@ -25,10 +25,6 @@ namespace sg {
 namespace {
 
 using namespace wavefft;
-
-constexpr int kS1 = 72, kS2 = 66;
-typedef float v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ v4f lds_get2(const float2* p) { return *(__attribute__((address_space(3))) volatile v4f*)(p); }
 
 template <int T> struct BlueCfg {
     static constexpr int R = 8 * T, M = 64 * R;                          // L = M complex points
@@ -64,27 +60,6 @@ struct BlueParams {
     float scale;
     int k_lo, k_hi;            // MODE 2: bins of the band
 };
-
-template <int T> __device__ __forceinline__ void radix_t(float2 (&v)[T]);
-template <> __device__ __forceinline__ void radix_t<1>(float2 (&)[1]) {}
-template <> __device__ __forceinline__ void radix_t<2>(float2 (&v)[2]) {
-    const float2 s = cadd(v[0], v[1]), d = csub(v[0], v[1]);
-    v[0] = s; v[1] = d;
-}
-template <> __device__ __forceinline__ void radix_t<4>(float2 (&v)[4]) {
-    const float2 s02 = cadd(v[0], v[2]), d02 = csub(v[0], v[2]);
-    const float2 s13 = cadd(v[1], v[3]), d13 = mul_mi(csub(v[1], v[3]));
-    v[0] = cadd(s02, s13); v[2] = csub(s02, s13);
-    v[1] = cadd(d02, d13); v[3] = csub(d02, d13);
-}
-
-// exp(-2*pi*i*n/R), R = 16 / 32: compile-time indices after unrolling
-template <int R> __device__ __forceinline__ float2 const_tw(int n) {
-    constexpr float kPi = 3.14159265358979323846f;
-    const int m = n & (R - 1);                               // (R = 8: never called with a0 > 0)
-    // (cosf / sinf of a constant fold at compile time)
-    return make_float2(__builtin_cosf(-2.0f * kPi * m / R), __builtin_sinf(-2.0f * kPi * m / R));
-}
 
 // MODE: 0 psd, 1 magnitude, 2 band power (A11)
 template <int T, bool DETREND, int MODE>
@@ -127,73 +102,10 @@ __global__ __launch_bounds__((64 * BlueCfg<T>::kWaves), (BlueCfg<T>::kOcc)) void
     int64_t g = p.total_frames * lw / p.n_waves;
     const int64_t g_end = p.total_frames * (lw + 1) / p.n_waves;
 
-    const float2* const t2 = lds + C::kTw2 + lane;                        // + 64*(s-1)
-    const int j0 = lane & 7, hi = lane >> 3;
-    float2* const x1w = buf + hi * kS1 + j0;                 // + 8*r1
-    float2* const x1r = buf + lane;                          // + b*kS1
-    float2* const x2w = buf + j0 * kS2 + hi;                 // + ((8q + R*s) % 64)   (group q3 = (8q + R*s) / 64)
-    float2* const x2r = buf + lane;                          // + j*kS2
+    const CfftLds fl = cfft_lds(lds + C::kTw1, lds + C::kTw2, buf, lane);       // the L-point transform of cfft_wave.h on this wave's slab
+    auto cfft = [&](float2 (&d)[T][8], float2 (&e)[T][8]) { cfft_wave<T>(d, e, fl); };
     const int n2 = p.n2;
     const float n_f = static_cast<float>(2 * n2);           // the mean is a true division (n is not a power of two: a constant clip must detrend to 0 exactly, as in scipy)
-
-    // L-point complex FFT in registers (passes and exchanges of stft_rbig.hip): in d[a0][a1] = y[lane + 64*(a0 + T*a1)] (destroyed),
-    // out e[q3][t] = Y[lane + 64*(q3 + T*t)] -- the same index form, so a second transform takes e as its d
-    auto cfft = [&](float2 (&d)[T][8], float2 (&e)[T][8]) {
-#pragma unroll
-        for (int a0 = 0; a0 < T; ++a0) {
-            radix8(d[a0]);                                 // over a1 -> r1
-            if (a0 > 0) {
-#pragma unroll
-                for (int r1 = 1; r1 < 8; ++r1) d[a0][r1] = cmul(d[a0][r1], const_tw<R>(a0 * r1));
-            }
-        }
-#pragma unroll
-        for (int r1 = 0; r1 < 8; ++r1) {                     // over a0 -> r0 ; r = r1 + 8*r0
-            float2 v[T];
-#pragma unroll
-            for (int a0 = 0; a0 < T; ++a0) v[a0] = d[a0][r1];
-            radix_t<T>(v);
-#pragma unroll
-            for (int r0 = 0; r0 < T; ++r0) d[r0][r1] = v[r0];
-        }
-#pragma unroll
-        for (int i = 0; i < R - 1; i += 2) {                 // table rows i, i + 1 <-> r = i + 1, i + 2
-            const v4f w = lds_get2(lds + C::kTw1 + (i >> 1) * 128 + 2 * lane);
-            d[(i + 1) / 8][(i + 1) % 8] = cmul(d[(i + 1) / 8][(i + 1) % 8], make_float2(w.x, w.y));
-            if (i + 2 < R) d[(i + 2) / 8][(i + 2) % 8] = cmul(d[(i + 2) / 8][(i + 2) % 8], make_float2(w.z, w.w));
-        }
-#pragma unroll
-        for (int q = 0; q < T; ++q) {                        // exchange 1, one group of 8 at a time through the slab
-#pragma unroll
-            for (int r1 = 0; r1 < 8; ++r1) lds_put(x1w + 8 * r1, d[q][r1]);
-            wave_lds_fence();
-#pragma unroll
-            for (int b = 0; b < 8; ++b) d[q][b] = lds_get(x1r + b * kS1);
-            wave_lds_fence();
-        }
-#pragma unroll
-        for (int q = 0; q < T; ++q) {                        // pass 2
-            radix8(d[q]);
-#pragma unroll
-            for (int s = 1; s < 8; ++s) d[q][s] = cmul(d[q][s], lds_get(t2 + 64 * (s - 1)));
-        }
-#pragma unroll
-        for (int q3 = 0; q3 < T; ++q3) {                     // exchange 2: group q3 collects the (q, s) with (8q + R*s) / 64 == q3
-#pragma unroll
-            for (int q = 0; q < T; ++q)
-#pragma unroll
-                for (int s = 0; s < 8; ++s) {
-                    const int uu = 8 * q + R * s;
-                    if (uu / 64 == q3) lds_put(x2w + (uu % 64), d[q][s]);
-                }
-            wave_lds_fence();
-#pragma unroll
-            for (int j = 0; j < 8; ++j) e[q3][j] = lds_get(x2r + j * kS2);
-            wave_lds_fence();
-        }
-#pragma unroll
-        for (int q3 = 0; q3 < T; ++q3) radix8(e[q3]);        // pass 3: e[q3][t] = Y[lane + 64*(q3 + T*t)]
-    };
 
     auto load_frame = [&](int clip, int f, float2 (&dst)[C::kRowsIn]) {
         const float* const src = p.x + static_cast<int64_t>(clip) * p.clip_stride + static_cast<int64_t>(f) * p.hop + 2 * lane;
@@ -349,8 +261,17 @@ int launch_t(const sg_plan& p, const StftArgs& a) {
                                             : launch_td<T, false>(prm, a.stream, p.mode, band, p.n_cu);
 }
 
+template <typename V>
+int upload(void** dev, const std::vector<V>& host) {
+    SG_HIP(hipMalloc(dev, host.size() * sizeof(V)));
+    SG_HIP(hipMemcpy(*dev, host.data(), host.size() * sizeof(V), hipMemcpyHostToDevice));
+    return SG_OK;
+}
+
+}  // namespace
+
 // Host-side double-precision radix-2 FFT, used once per plan for the filter spectrum
-void host_fft(std::vector<double>& re, std::vector<double>& im) {
+void host_fft_pow2(std::vector<double>& re, std::vector<double>& im) {
     const size_t n = re.size();
     for (size_t i = 1, j = 0; i < n; ++i) {
         size_t bit = n >> 1;
@@ -372,15 +293,6 @@ void host_fft(std::vector<double>& re, std::vector<double>& im) {
         }
     }
 }
-
-template <typename V>
-int upload(void** dev, const std::vector<V>& host) {
-    SG_HIP(hipMalloc(dev, host.size() * sizeof(V)));
-    SG_HIP(hipMemcpy(*dev, host.data(), host.size() * sizeof(V), hipMemcpyHostToDevice));
-    return SG_OK;
-}
-
-}  // namespace
 
 int rblue_size(int nfft) { return nfft <= 512 ? 1 : nfft <= 1024 ? 2 : 4; }     // T of a plan rblue_ok() accepts
 
@@ -418,7 +330,7 @@ int build_rblue_tables(sg_plan& p, const std::vector<double>& window) {
     std::vector<double> hr(M, 0.0), hi(M, 0.0);
     hr[0] = cr[0]; hi[0] = ci[0];
     for (int j = 1; j < n2; ++j) { hr[j] = hr[M - j] = cr[j]; hi[j] = hi[M - j] = ci[j]; }
-    host_fft(hr, hi);
+    host_fft_pow2(hr, hi);
     std::vector<float2> filt(M);
     for (int k = 0; k < M; ++k) filt[k] = make_float2(static_cast<float>(hr[k] / M), static_cast<float>(hi[k] / M));
     std::vector<float2> stw(static_cast<size_t>(rows_out) * 64, make_float2(0.f, 0.f));

@@ -1007,6 +1007,90 @@ def test_rblue_band_power_int16_and_fallbacks(sp, n, hop):
 
 
 @pytest.mark.parametrize("n,hop,detrend,mode,window", [
+    (3000, 750, "constant", "psd", "hann"), (2080, 1820, "constant", "psd", ("tukey", 0.25)), (2052, 513, False, "magnitude", "hann"),
+    (4092, 1024, "constant", "psd", "boxcar"), (4064, 508, False, "psd", "hann"),
+    (6000, 1500, "constant", "psd", "hann"), (8160, 7140, "constant", "psd", ("tukey", 0.25)), (4104, 1027, False, "magnitude", "hann"),
+    (8184, 2046, "constant", "psd", "boxcar"), (5120, 640, "constant", "magnitude", "hann")])
+def test_rbluew_kernel(sp, n, hop, detrend, mode, window):
+    """nperseg 2080 ... 8192 that is no power of two (the GUI's spin box runs to 8192 in steps of 32, GUI.py:87-89): the wide register
+    chirp-z kernel (stft_rbluew.hip, round 4: two wavefronts per frame up to 4096, four above) against the oracle -- several clips incl.
+    all-zero and constant ones, odd hops, the reference's own hop n - n // 8 -- and against the LDS chirp-z kernel of the same plan."""
+    from spectro import _capi
+    from spectro.signal import plan_for
+    from spectro.windows import get_window
+    rng = np.random.default_rng(n + hop)
+    N = n + hop * 11 + 6
+    x = (rng.standard_normal((5, N)) * 0.4 + 0.2).astype(np.float32)
+    x[2] = 0.0
+    x[3] = -7.5
+    kw = dict(fs=48000.0, nperseg=n, window=window, noverlap=n - hop, detrend=detrend, mode=mode)
+    plan = plan_for(get_window(window, n), n, n, hop, _capi.DETREND[detrend], 48000.0, 0, _capi.MODE[mode], _capi.F32)
+    assert plan.kernel == "rbluew"
+    f, t, s = sp.spectrogram(x, **kw)
+    fo, to, so = orc.spectrogram(x, **kw)
+    np.testing.assert_array_equal(f, fo)
+    np.testing.assert_array_equal(t, to)
+    assert s.dtype == np.float32 and s.shape == so.shape
+    floor = 1e-3 if mode == "psd" else 1e-3 ** 0.5
+    keep = [0, 1, 4] if detrend else [0, 1, 3, 4]
+    assert_spec_close(s[keep], so[keep], time_axis=-1, bin_floor=floor)
+    assert np.all(s[2] == 0.0)
+    if detrend:
+        assert np.abs(s[3]).max() <= 1e-7 * np.abs(s[0]).max()
+    plan.force_kernel("bluestein")
+    try:
+        _, _, s_lds = sp.spectrogram(x, **kw)
+    finally:
+        plan.force_kernel("rbluew")
+    assert_spec_close(s[keep], s_lds[keep], time_axis=-1, bin_floor=floor)
+
+
+@pytest.mark.parametrize("n,hop,clips,frames", [(2080, 64, 3, 701), (4128, 96, 2, 1031), (2400, 32, 1, 1025), (8000, 4000, 1, 1)])
+def test_rbluew_many_frames_band_power_and_int16(sp, n, hop, clips, frames):
+    """More frames than the launch has frame groups (1 024 / 512: every group loops, the last pass is ragged) and a single frame; the fused
+    band power (A11) == the sum over the written bins; int16 batches (converted once on the device) == the float call; clips at an
+    odd stride take the 4-byte loads."""
+    from spectro import _capi
+    from spectro.signal import plan_for
+    from spectro.windows import get_window
+    rng = np.random.default_rng(n * 7 + hop)
+    ns = n + hop * (frames - 1) + 3
+    x = (rng.standard_normal((clips, ns)) * 0.3 + 0.5).astype(np.float32)
+    plan = plan_for(get_window("hann", n), n, n, hop, 1, 48000.0, 0, 0, _capi.F32)
+    assert plan.kernel == "rbluew"
+    kw = dict(fs=48000.0, nperseg=n, window="hann", noverlap=n - hop)
+    _, _, s = sp.spectrogram(x, **kw)
+    _, _, so = orc.spectrogram(x, **kw)
+    assert s.shape == so.shape == (clips, n // 2 + 1, frames)
+    # (per-bin bound 3e-4 over these 1-2 M bins: the tail of float32 rounding at bins 1e-3 of the frame maximum -- scipy's own float32
+    # path shows 1.8e-4 / 2.0e-4 on the same inputs, this kernel 1.3e-4 / 1.7e-4, tools/acc_np2.py; frame and norm bounds as everywhere)
+    assert_spec_close(s, so, time_axis=-1, bin_rtol=3e-4)
+    nfr, nb = plan.n_frames(ns), n // 2 + 1
+    d_in, d_bp = _capi.DeviceBuffer(x.nbytes), _capi.DeviceBuffer(clips * nfr * 4)
+    d_in.upload(x)
+    h = n // 2
+    spec = np.moveaxis(s, -1, -2).astype(np.float64)
+    for k_lo, k_hi in [(0, h), (1, 7), (h, h), (h // 2, h - 1), (63, 64)]:
+        _capi.check(_capi.lib().sg_memset(C.c_void_p(d_bp.ptr), 0xFF, clips * nfr * 4, None))
+        plan.band_power(d_in.ptr, ns, ns, clips, k_lo, k_hi, d_bp.ptr, nfr)
+        bp = np.empty((clips, nfr), np.float32)
+        d_bp.download(bp)
+        _capi.stream_sync()
+        ref = spec[:, :, k_lo:k_hi + 1].sum(-1)
+        assert np.all(np.abs(bp - ref) <= 2e-6 * spec.sum(-1) + 1e-30), (k_lo, k_hi)
+    d_in.free(); d_bp.free()
+    xi = np.round(x[:, :n + hop * min(frames - 1, 40) + 1] * 8000).astype(np.int16)
+    _, _, s_i = sp.spectrogram(xi, **kw)
+    _, _, s_f = sp.spectrogram(xi.astype(np.float32), **kw)
+    np.testing.assert_array_equal(s_i, s_f)
+    if clips > 1:
+        xs = x[:, :ns - 1] if (ns - 1) % 2 else x[:, :ns - 2]
+        _, _, s1 = sp.spectrogram(xs, **kw)
+        _, _, so1 = orc.spectrogram(xs, **kw)
+        assert_spec_close(s1, so1, time_axis=-1, bin_rtol=3e-4)
+
+
+@pytest.mark.parametrize("n,hop,detrend,mode,window", [
     (1000, 250, "constant", "psd", "hann"), (1000, 875, "constant", "psd", ("tukey", 0.25)), (960, 240, False, "magnitude", "hann"),
     (96, 24, "constant", "psd", ("tukey", 0.25)), (480, 419, "constant", "psd", "hann"), (6, 2, "constant", "psd", "boxcar"),
     (34, 30, False, "psd", "hann"), (1022, 2, "constant", "magnitude", "hann"), (514, 128, "constant", "psd", "boxcar")])
