@@ -70,6 +70,14 @@ static bool rbluew_ok(const sg_plan& p) {
            (p.mode == SG_MODE_PSD || p.mode == SG_MODE_MAGNITUDE);
 }
 
+// ... in double precision from 1024: two / four / eight wavefronts per frame (stft_rbluew_f64.hip), nperseg a multiple of 4 / 8 / 16
+static bool rbluewd_ok(const sg_plan& p) {
+    return p.dtype == SG_F64 && p.nperseg == p.nfft && !is_pow2(p.nfft) && p.nfft > 1024 && p.nfft <= 8192 &&
+           p.nfft % (2 * rbluew_f64_size(p.nfft)) == 0 &&
+           (p.detrend == SG_DETREND_NONE || p.detrend == SG_DETREND_CONSTANT) &&
+           (p.mode == SG_MODE_PSD || p.mode == SG_MODE_MAGNITUDE);
+}
+
 static bool stockham_ok(const sg_plan& p) {
     if (!is_pow2(p.nfft) || p.nfft < 2) return false;
     // LDS need of the largest case: one frame per workgroup, two nfft-real buffers + reduction scratch
@@ -233,6 +241,10 @@ static int run_stft(const sg_plan* plan, StftArgs& a) {
         // (more than 2^31 frames per clip: the LDS chirp-z kernel, whose tables this plan builds on first need)
         case Kernel::RBLUED:
             if (rblue_f64_can_run(*plan, a)) return launch_rblue_f64(*plan, a);
+            if (a.band_mode) { set_error("band power of this chirp-z plan needs 8-byte aligned float64 input"); return SG_ERR_UNSUPPORTED; }
+            return launch_bluestein_lazy(plan, a);
+        case Kernel::RBLUEWD:
+            if (rbluew_f64_can_run(*plan, a)) return launch_rbluew_f64(*plan, a);
             if (a.band_mode) { set_error("band power of this chirp-z plan needs 8-byte aligned float64 input"); return SG_ERR_UNSUPPORTED; }
             return launch_bluestein_lazy(plan, a);
         case Kernel::RBLUE: return rblue_can_run(*plan, a) ? launch_rblue(*plan, a) : a.band_mode ? band_via_spectrum(plan, a) : launch_bluestein_lazy(plan, a);
@@ -403,6 +415,9 @@ int sg_plan_create(sg_plan** plan, int nperseg, int nfft, int hop, const double*
         } else if (rbluew_ok(*p)) {
             p->kernel = Kernel::RBLUEW;
             rc = build_rbluew_tables(*p, w);
+        } else if (rbluewd_ok(*p)) {
+            p->kernel = Kernel::RBLUEWD;
+            rc = build_rbluew_f64_tables(*p, w);
         } else {
             p->kernel = Kernel::BLUESTEIN;
             rc = build_bluestein_tables(*p);
@@ -451,6 +466,7 @@ const char* sg_plan_kernel(const sg_plan* plan) {
         case Kernel::RBLUE: return "rblue";
         case Kernel::RBLUED: return "rblued";
         case Kernel::RBLUEW: return "rbluew";
+        case Kernel::RBLUEWD: return "rbluewd";
     }
     return "";
 }
@@ -501,6 +517,11 @@ int sg_plan_force_kernel(sg_plan* plan, const char* name) {
         if (!rblue_ok(*plan)) { set_error("plan cannot run on rblue"); return SG_ERR_UNSUPPORTED; }
         if (!plan->rb_wc_dev) { set_error("rblue tables are built with the plan only"); return SG_ERR_UNSUPPORTED; }
         plan->kernel = Kernel::RBLUE;
+        return SG_OK;
+    }
+    if (!strcmp(name, "rbluewd")) {
+        if (!rbluewd_ok(*plan) || !plan->rb_wc_dev) { set_error("plan cannot run on rbluewd"); return SG_ERR_UNSUPPORTED; }
+        plan->kernel = Kernel::RBLUEWD;
         return SG_OK;
     }
     if (!strcmp(name, "rbluew")) {

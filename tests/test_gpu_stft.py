@@ -1091,6 +1091,75 @@ def test_rbluew_many_frames_band_power_and_int16(sp, n, hop, clips, frames):
 
 
 @pytest.mark.parametrize("n,hop,detrend,mode,window", [
+    (1056, 264, "constant", "psd", "hann"), (2000, 1750, "constant", "psd", ("tukey", 0.25)), (1028, 257, False, "magnitude", "hann"),
+    (2044, 512, "constant", "psd", "boxcar"),
+    (3000, 750, "constant", "psd", "hann"), (4088, 3577, "constant", "psd", ("tukey", 0.25)), (2056, 515, False, "magnitude", "hann"),
+    (6000, 1500, "constant", "psd", "hann"), (8160, 7140, "constant", "psd", ("tukey", 0.25)), (4112, 1029, False, "magnitude", "hann"),
+    (8176, 2044, "constant", "psd", "boxcar")])
+def test_rbluew_f64_kernel(sp, n, hop, detrend, mode, window):
+    """The reference's own flow at nperseg 1056 ... 8160 (float64 recordings, SweepManager.py:135-136; the spin box runs to 8192 in steps
+    of 32, GUI.py:87-89): the wide double-precision register chirp-z kernel (stft_rbluew_f64.hip, round 4: two / four / eight wavefronts
+    per frame) against the oracle at f64 tolerance, against the LDS kernel of the same plan, the fused band power, odd hops (the
+    reference's literal hop is n - n // 8) and clips at an odd stride."""
+    from spectro import _capi
+    from spectro.signal import plan_for
+    from spectro.windows import get_window
+    rng = np.random.default_rng(n * 3 + hop)
+    N = n + hop * 11 + 6
+    x = rng.standard_normal((5, N)) * 0.4 + 0.2
+    x[2] = 0.0
+    x[3] = -7.5
+    kw = dict(fs=48000.0, nperseg=n, window=window, noverlap=n - hop, detrend=detrend, mode=mode)
+    plan = plan_for(get_window(window, n), n, n, hop, _capi.DETREND[detrend], 48000.0, 0, _capi.MODE[mode], _capi.F64)
+    assert plan.kernel == "rbluewd"
+    f, t, s = sp.spectrogram(x, **kw)
+    fo, to, so = orc.spectrogram(x, **kw)
+    np.testing.assert_array_equal(f, fo)
+    np.testing.assert_array_equal(t, to)
+    keep = [0, 1, 4] if detrend else [0, 1, 3, 4]
+    _check(s[keep], so[keep], np.float64)
+    assert np.all(s[2] == 0.0)
+    if detrend:
+        assert np.abs(s[3]).max() <= 1e-20 * max(np.abs(s[0]).max(), 1e-300) + 1e-28
+    plan.force_kernel("bluestein")
+    try:
+        _, _, s_lds = sp.spectrogram(x, **kw)
+    finally:
+        plan.force_kernel("rbluewd")
+    _check(s[keep], s_lds[keep], np.float64)
+    xs = x[:, :N - 1] if (N - 1) % 2 else x[:, :N - 2]       # clips at an odd stride: 8-byte loads
+    _, _, s1 = sp.spectrogram(xs, **kw)
+    _, _, so1 = orc.spectrogram(xs, **kw)
+    _check(s1[keep], so1[keep], np.float64)
+    if mode == "psd":                                        # fused band power == the sum over the written bins
+        nfr = plan.n_frames(N)
+        d_in, d_bp = _capi.DeviceBuffer(x.nbytes), _capi.DeviceBuffer(5 * nfr * 8)
+        d_in.upload(np.ascontiguousarray(x))
+        h = n // 2
+        for k_lo, k_hi in [(0, h), (1, 7), (h, h), (h // 2, h - 1), (63, 64)]:
+            plan.band_power(d_in.ptr, N, N, 5, k_lo, k_hi, d_bp.ptr, nfr)
+            bp = np.empty((5, nfr), np.float64)
+            d_bp.download(bp)
+            _capi.stream_sync()
+            ref = np.moveaxis(s, -1, -2)[:, :, k_lo:k_hi + 1].sum(-1)
+            assert np.all(np.abs(bp - ref) <= 1e-12 * np.moveaxis(s, -1, -2).sum(-1) + 1e-300), (k_lo, k_hi)
+        d_in.free(); d_bp.free()
+
+
+@pytest.mark.parametrize("n,hop,clips,frames", [(1056, 32, 3, 701), (2080, 48, 2, 531), (4112, 16, 1, 259), (4112, 2000, 1, 1)])
+def test_rbluew_f64_many_frames(sp, n, hop, clips, frames):
+    """More frames than the launch has frame groups (1 024 / 512 / 256: every group loops, the last pass is ragged) and a single frame."""
+    rng = np.random.default_rng(n * 5 + hop)
+    ns = n + hop * (frames - 1) + 3
+    x = rng.standard_normal((clips, ns)) * 0.3 + 0.5
+    kw = dict(fs=48000.0, nperseg=n, window="hann", noverlap=n - hop)
+    _, _, s = sp.spectrogram(x, **kw)
+    _, _, so = orc.spectrogram(x, **kw)
+    assert s.shape == so.shape == (clips, n // 2 + 1, frames)
+    _check(s, so, np.float64)
+
+
+@pytest.mark.parametrize("n,hop,detrend,mode,window", [
     (1000, 250, "constant", "psd", "hann"), (1000, 875, "constant", "psd", ("tukey", 0.25)), (960, 240, False, "magnitude", "hann"),
     (96, 24, "constant", "psd", ("tukey", 0.25)), (480, 419, "constant", "psd", "hann"), (6, 2, "constant", "psd", "boxcar"),
     (34, 30, False, "psd", "hann"), (1022, 2, "constant", "magnitude", "hann"), (514, 128, "constant", "psd", "boxcar")])
