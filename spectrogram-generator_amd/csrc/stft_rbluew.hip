@@ -216,15 +216,19 @@ __global__ __launch_bounds__((64 * WideCfg<W>::kWaves), 2) void stft_rbluew_kern
         if (w == 0 && lane == 0) lds_put(region + n2, z[0]);                     // Z[N2] := Z[0]
         __syncthreads();                                     // (3)
         // ---- split + epilogue: this wave's rows of the bins k = 0..N2 ----------------------------------------------------------------------
+        // (row addresses are rebuilt per frame from opaque copies of w and N2: hoisted out of the loop they are three registers per row
+        //  held across the transforms)
         float bsum = 0.f;
+        int w_d = w, n2_d = n2;
+        asm volatile("" : "+s"(w_d), "+s"(n2_d));
 #pragma unroll
         for (int cc = 0; cc < C::kRowsD; ++cc) {
-            const int rho = w + W * cc;
+            const int rho = w_d + W * cc;
             if (64 * rho <= n2) {                            // wave-uniform
                 const int k = lane + 64 * rho;
-                const int kk = k <= n2 ? k : n2;             // lanes beyond the last bin read a valid entry and store nothing
+                const int kk = k <= n2_d ? k : n2_d;         // lanes beyond the last bin read a valid entry and store nothing
                 const float2 A = lds_get(region + kk);
-                const float2 B = lds_get(region + (n2 - kk));
+                const float2 B = lds_get(region + (n2_d - kk));
                 const float2 tw = cmul(lane_tw, lds_get(lds + C::kSrow + 64 + rho));
                 const float2 S = make_float2(A.x + B.x, A.y - B.y);
                 const float2 D = make_float2(A.x - B.x, A.y + B.y);

@@ -11,17 +11,14 @@
 // are separate real / imaginary planes (ds_*_b64 only); the window rows of a wave are loop-invariant and live in REGISTERS (16 doubles per
 // lane), which is what lets tables (57 KB) and exchange slabs (74 KB) of eight waves fit the LDS at every W; four workgroup barriers per frame,
 // the frame mean riding on the prefetched samples of the next frame as there (prefetch issued after the second transform, its partial sums
-// exchanged with Z: the register file has no room for it during the transforms).
+// exchanged with Z: the register file has no room for it during the transforms).  W = 8 has no room for either across the transforms (190-390
+// spilled dwords per lane when tried): its waves fetch samples and window rows at the top of the frame and the mean costs a fifth barrier.
 // Algorithmic HBM bytes per frame: hop*8 + (n/2+1)*8.
 #include "spectro_internal.h"
 #include "cfft_wave_f64.h"
 
 #include <cmath>
 #include <vector>
-
-#ifndef SG_RBLUEWD_WIN_RELOAD
-#define SG_RBLUEWD_WIN_RELOAD 8
-#endif
 
 namespace sg {
 namespace {
@@ -32,7 +29,7 @@ template <int W> struct WideDCfg {
     static constexpr int T = 2, R = 8 * T, M = 64 * R;                   // the sub-transform: L = 1024
     static constexpr int kWaves = 8, kGroups = kWaves / W;               // per workgroup
     static constexpr int kRows = 8;                                      // rows of 64 points a wave fills: mp <= 512
-    static constexpr int kWinReload = SG_RBLUEWD_WIN_RELOAD;             // from this W on the window rows are fetched per frame
+    static constexpr bool kPrefetch = W < 8;                             // W = 8: no room for the next frame's samples or resident window rows next to the transforms
     static constexpr int kRowsD = 9;                                     // rows of output bins per wave: (N2 + 1 <= W * 512 + 1) / 64 / W, rounded up
     static constexpr int kRegion = W * kSlab + 8;                        // elements per plane and frame group: the waves' exchange slabs; then G_w[k0]; then Z[0..N2]
     // complex table entries (each a real and an imaginary plane element) -- the device table has this order, then the window rows
@@ -88,11 +85,12 @@ __global__ __launch_bounds__((64 * WideDCfg<W>::kWaves), 2) void stft_rbluew_f64
 
     // per-lane views: every access below is one of these bases plus a compile-time offset (with a full index expression per access the
     // compiler keeps an address register per table row and plane -- ~90 at W = 8 -- and spills them)
-    const Planes tab_l = tab.at(lane), region_l = region.at(lane), sl_l = sl.at(lane);
+    const Planes tab_l = tab.at(lane), sl_l = sl.at(lane);
+    const Planes region_l = region.at(lane);
     const int n2 = p.n2, mp = p.mp;
     const double n_f = static_cast<double>(2 * n2);
     const cd lane_tw = tab.get(C::kSrow + lane);
-    // this wave's window rows are loop-invariant: kept in registers where the transforms leave room (W < kWinReload), else fetched again
+    // this wave's window rows are loop-invariant: kept in registers where the transforms leave room (kPrefetch), else fetched again
     // with every frame's samples (L2 hits); sqrt of the PSD scale rides on them
     cd win[C::kRows];
     const double sq = sqrt(MODE != 1 ? p.scale * 0.5 : p.scale * 0.25);           // bins 0 and N2 get 1/2 below
@@ -103,7 +101,7 @@ __global__ __launch_bounds__((64 * WideDCfg<W>::kWaves), 2) void stft_rbluew_f64
             win[a] = {v.x * sq, v.y * sq};
         }
     };
-    load_window();
+    if (C::kPrefetch) load_window();
     const int lg = xcd_remap(blockIdx.x, gridDim.x) * C::kGroups + grp;
     int64_t g = lg < p.n_groups ? p.total_frames * lg / p.n_groups : 0;
     const int64_t g_end = lg < p.n_groups ? p.total_frames * (lg + 1) / p.n_groups : 0;
@@ -138,9 +136,9 @@ __global__ __launch_bounds__((64 * WideDCfg<W>::kWaves), 2) void stft_rbluew_f64
     };
 
     cd nxt[C::kRows];
-    load_frame(clip, f, nxt);                                // (a group without frames reads frame 0 of clip 0 and stores nothing)
+    if (C::kPrefetch) load_frame(clip, f, nxt);              // (a group without frames reads frame 0 of clip 0 and stores nothing)
     double mean = 0.0;
-    if (DETREND) {
+    if (DETREND && C::kPrefetch) {
         const double s = part_sum(nxt);
         if (lane == 0) psum[w] = s;
         __syncthreads();
@@ -153,6 +151,16 @@ __global__ __launch_bounds__((64 * WideDCfg<W>::kWaves), 2) void stft_rbluew_f64
         double* const orow = p.out + static_cast<int64_t>(clip) * p.out_clip_stride + static_cast<int64_t>(f) * (MODE == 2 ? 1 : n2 + 1);
         const bool more = g + 1 < g_end;
         const int clip_n = !more ? clip : f + 1 == p.n_frames ? clip + 1 : clip, f_n = !more ? f : f + 1 == p.n_frames ? 0 : f + 1;
+        if (!C::kPrefetch) {                                 // samples and window rows fetched here; the mean costs a fifth barrier
+            load_window();
+            load_frame(clip, f, nxt);
+            if (DETREND) {
+                const double s = part_sum(nxt);
+                if (lane == 0) psum[w] = s;
+                __syncthreads();
+                mean = group_mean();
+            }
+        }
         cd d[T][8], e[T][8];
         // ---- a[m] = (x[2j] w[2j] + i x[2j+1] w[2j+1]) * c[a], j = W a + w; rows beyond mp are zero (their window entries are) ----
 #pragma unroll
@@ -171,8 +179,7 @@ __global__ __launch_bounds__((64 * WideDCfg<W>::kWaves), 2) void stft_rbluew_f64
             d[c % T][c / T] = cd{y.x, -y.y};
         }
         cfft_wave_f64<T>(d, e, tab, C::kTw1, C::kTw2, sl, lane);             // e = V; the convolution is conj(V) (1 / L is in B)
-        if (W >= C::kWinReload) load_window();
-        load_frame(clip_n, f_n, nxt);                        // prefetch, issued where the register file has room for it (the group's last frame fetches itself again)
+        if (C::kPrefetch) load_frame(clip_n, f_n, nxt);      // prefetch, issued where the register file has room for it (the group's last frame fetches itself again)
         // ---- G_w[k0] = W_N2^(w k0) * c[k0] * conj(V[k0]) -> this wave's slab ----
 #pragma unroll
         for (int c = 0; c < C::kRows; ++c) {
@@ -223,21 +230,25 @@ __global__ __launch_bounds__((64 * WideDCfg<W>::kWaves), 2) void stft_rbluew_f64
         for (int c = 0; c < C::kRows; ++c)
             if (lane + 64 * c < mp) zrow.put(64 * c, z[c]);
         if (w == 0 && lane == 0) region.put(n2, z[0]);       // Z[N2] := Z[0]
-        if (DETREND) {                                       // the next frame's samples have arrived by now: their partial sum travels with Z
+        if (DETREND && C::kPrefetch) {                       // the next frame's samples have arrived by now: their partial sum travels with Z
             const double s = part_sum(nxt);
             if (lane == 0) psum[w] = s;
         }
         __syncthreads();                                     // (3)
-        if (DETREND) mean = group_mean();
+        if (DETREND && C::kPrefetch) mean = group_mean();
         // ---- split + epilogue: this wave's rows of the bins k = 0..N2 ----
+        // (row addresses are rebuilt per frame from opaque copies of w and N2: hoisted out of the loop they are five registers per row
+        //  that the transforms need)
         double bsum = 0.0;
+        int w_d = w, n2_d = n2;
+        asm volatile("" : "+s"(w_d), "+s"(n2_d));
 #pragma unroll
         for (int cc = 0; cc < C::kRowsD; ++cc) {
-            const int rho = w + W * cc;
+            const int rho = w_d + W * cc;
             if (64 * rho <= n2) {                            // wave-uniform
                 const int k = lane + 64 * rho;
-                const int kk = k <= n2 ? k : n2;             // lanes beyond the last bin read a valid entry and store nothing
-                const cd A = region.get(kk), B = region.get(n2 - kk);
+                const int kk = k <= n2_d ? k : n2_d;         // lanes beyond the last bin read a valid entry and store nothing
+                const cd A = region.get(kk), B = region.get(n2_d - kk);
                 const cd tw = cmul(lane_tw, tab.get(C::kSrow + 64 + rho));
                 const cd S = {A.x + B.x, A.y - B.y};
                 const cd D = {A.x - B.x, A.y + B.y};
