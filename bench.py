@@ -603,6 +603,19 @@ def time_secondary(_capi, get_window, xs, dev, stream):
         pn.close()
         del o2
     out["nperseg_1000"] = np2
+    # ... and above 2048: nperseg 4000 at hop 1000 and at the reference's own hop 3500 (two wavefronts per frame, stft_rbluew.hip)
+    np2w = {}
+    for hop_np2 in (1000, 3500):
+        pn = _capi.Plan(4000, 4000, hop_np2, get_window("hann" if hop_np2 == 1000 else ("tukey", 0.25), 4000), _capi.DETREND["constant"], FS,
+                        _capi.SCALING["density"], _capi.MODE["psd"], _capi.F32)
+        nf = pn.n_frames(N_SAMPLES)
+        o2 = [torch.empty((n_clips, nf, 2001), device=dev, dtype=torch.float32) for _ in range(2)]
+        us = timed(lambda i: pn.stft(xs[i % len(xs)].data_ptr(), N_SAMPLES, N_SAMPLES, n_clips, o2[i % 2].data_ptr(), nf * 2001, stream=stream), 24, settle_s=0.05, budget_s=0.0)
+        np2w[f"hop_{hop_np2}"] = {"kernel": pn.kernel, "frames": n_clips * nf, "us": us, "frames_per_s": n_clips * nf / us * 1e6,
+                                  "bytes_per_frame": hop_np2 * 4 + 2001 * 4, "frac_of_hbm_peak": n_clips * nf * (hop_np2 * 4 + 2001 * 4) / us / 1e3 / HBM_PEAK_GBS}
+        pn.close()
+        del o2
+    out["nperseg_4000"] = np2w
 
     # ---- cfg5: streaming 8 ch x 96 kHz, n_fft 4096 hop 1024, 4096-sample chunks, synchronous feed() host to host (PCIe inclusive)
     st = StreamingSTFT(8, 96000.0, 4096, 1024, window="hann")
