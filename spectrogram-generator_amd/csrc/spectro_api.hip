@@ -31,7 +31,7 @@ static bool r8x3d_ok(const sg_plan& p) {
 }
 
 static bool rsmall_ok(const sg_plan& p) {
-    return p.dtype == SG_F32 && p.nperseg == p.nfft && (p.nfft == 256 || p.nfft == 512) &&
+    return p.dtype == SG_F32 && p.nperseg == p.nfft && (p.nfft == 128 || p.nfft == 256 || p.nfft == 512) &&
            (p.detrend == SG_DETREND_NONE || p.detrend == SG_DETREND_CONSTANT) &&
            (p.mode == SG_MODE_PSD || p.mode == SG_MODE_MAGNITUDE);
 }
@@ -64,7 +64,8 @@ static bool rblued_ok(const sg_plan& p) {
 
 // ... and from 2048 to 8192 with two / four wavefronts per frame (stft_rbluew.hip): nperseg a multiple of 4 / 8
 static bool rbluew_ok(const sg_plan& p) {
-    return p.dtype == SG_F32 && p.nperseg == p.nfft && !is_pow2(p.nfft) && p.nfft > 2048 && p.nfft <= 8192 &&
+    // (8192 itself too: a chirp-z transform over four waves is 2.2 x the Stockham kernel there, profiles/r04_pow2_edges.txt)
+    return p.dtype == SG_F32 && p.nperseg == p.nfft && (!is_pow2(p.nfft) || p.nfft == 8192) && p.nfft > 2048 && p.nfft <= 8192 &&
            p.nfft % (2 * rbluew_size(p.nfft)) == 0 &&
            (p.detrend == SG_DETREND_NONE || p.detrend == SG_DETREND_CONSTANT) &&
            (p.mode == SG_MODE_PSD || p.mode == SG_MODE_MAGNITUDE);
@@ -72,7 +73,7 @@ static bool rbluew_ok(const sg_plan& p) {
 
 // ... in double precision from 1024: two / four / eight wavefronts per frame (stft_rbluew_f64.hip), nperseg a multiple of 4 / 8 / 16
 static bool rbluewd_ok(const sg_plan& p) {
-    return p.dtype == SG_F64 && p.nperseg == p.nfft && !is_pow2(p.nfft) && p.nfft > 1024 && p.nfft <= 8192 &&
+    return p.dtype == SG_F64 && p.nperseg == p.nfft && (!is_pow2(p.nfft) || p.nfft == 8192) && p.nfft > 1024 && p.nfft <= 8192 &&
            p.nfft % (2 * rbluew_f64_size(p.nfft)) == 0 &&
            (p.detrend == SG_DETREND_NONE || p.detrend == SG_DETREND_CONSTANT) &&
            (p.mode == SG_MODE_PSD || p.mode == SG_MODE_MAGNITUDE);
@@ -404,7 +405,7 @@ int sg_plan_create(sg_plan** plan, int nperseg, int nfft, int hop, const double*
         } else if (rbigd_ok(*p)) {
             p->kernel = Kernel::RBIGD;
             rc = build_rbig_f64_tables(*p);
-        } else if (stockham_ok(*p)) {
+        } else if (stockham_ok(*p) && !(p->nfft == 8192 && (rbluew_ok(*p) || rbluewd_ok(*p)))) {
             p->kernel = Kernel::STOCKHAM;
         } else if (rblued_ok(*p)) {
             p->kernel = Kernel::RBLUED;

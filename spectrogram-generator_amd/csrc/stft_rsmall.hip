@@ -1,5 +1,6 @@
 // stft_rsmall.hip -- register FFT kernel for the small transforms of the parameter sweep (BASELINE cfg4):
-// nperseg = nfft = 128*R with R = 2 (256) or R = 4 (512), f32, detrend none|constant, psd|magnitude.
+// nperseg = nfft = 128*R with R = 2 (256) or R = 4 (512), f32, detrend none|constant, psd|magnitude -- and R = 1 (128, eight frames per
+// wave, no pass 1: round 4; the spin box starts at 32 and steps by 32, /root/reference/GUI.py:87-89).
 //
 // Same machine mapping as stft_r8x3.hip (one wavefront, 8 complex values per lane, three register passes, two
 // padded LDS transposes, split pass with only the upper half crossing lanes, no s_barrier in the frame loop), but a
@@ -62,6 +63,7 @@ template <int L> __device__ __forceinline__ float group_sum(float v) {      // o
 }
 
 template <int R> __device__ __forceinline__ void radix_small(float2* a);
+template <> __device__ __forceinline__ void radix_small<1>(float2*) {}
 template <> __device__ __forceinline__ void radix_small<2>(float2* a) {
     const float2 s = cadd(a[0], a[1]), d = csub(a[0], a[1]);
     a[0] = s; a[1] = d;
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(64 * kWaves) void stft_rsmall_kernel(const SmallPar
     const int64_t q_end = p.total_groups * (lw + 1) / p.n_waves;
 
     // per-lane constants
-    float2 w[R], t1[R - 1], t2[7], t3[4];
+    float2 w[R], t1[R > 1 ? R - 1 : 1], t2[7], t3[4];
 #pragma unroll
     for (int a = 0; a < R; ++a) w[a] = p.win2[lane + 64 * a];
 #pragma unroll
@@ -311,7 +313,7 @@ bool rsmall_can_run(const sg_plan& p, const StftArgs& a) {
 
 int launch_rsmall(const sg_plan& p, const StftArgs& a) {
     if (a.n_frames <= 0 || a.n_clips <= 0) return SG_OK;
-    return p.nfft == 256 ? launch_r<2>(p, a) : launch_r<4>(p, a);
+    return p.nfft == 128 ? launch_r<1>(p, a) : p.nfft == 256 ? launch_r<2>(p, a) : launch_r<4>(p, a);
 }
 
 // Per-lane twiddle table [(R-1) + 7 + 4][64] float2 (R = nfft/128), computed in double:

@@ -103,7 +103,7 @@ def test_r8x3_variants(sp, hop, detrend, mode):
     assert_spec_close(s, so, time_axis=-1)
 
 
-@pytest.mark.parametrize("nperseg,hop", [(256, 64), (512, 128), (512, 127), (1024, 256), (2048, 128), (4096, 1024), (2048, 333), (1000, 250)])
+@pytest.mark.parametrize("nperseg,hop", [(128, 32), (256, 64), (512, 128), (512, 127), (1024, 256), (2048, 128), (4096, 1024), (2048, 333), (1000, 250), (4000, 1000)])
 def test_int16_pcm_batches_every_family(sp, nperseg, hop):
     """int16 PCM (16-bit WAV): the result must equal the float call on the same values BIT FOR BIT in every kernel family -- r8x3
     and the LDS kernel load int16 themselves, rsmall / rbig batches convert once into a stream-ordered workspace
@@ -157,7 +157,7 @@ def test_int16_batches_many_calls_in_a_row(sp):
 
 @pytest.mark.parametrize("nperseg,hop", [(1024, 64), (1024, 32), (1024, 16), (2048, 64), (2048, 128), (2048, 256), (2048, 32),
                                          (4096, 64), (4096, 128), (4096, 256), (4096, 16),
-                                         (256, 128), (256, 64), (256, 16), (512, 128), (512, 64), (512, 32)])
+                                         (256, 128), (256, 64), (256, 16), (512, 128), (512, 64), (512, 32), (128, 32), (128, 16), (128, 128)])
 def test_sliding_window_walks(sp, nperseg, hop):
     """Register sliding windows: hops 128 / 256 directly, hops 64 / 32 / 16 as 2 / 4 / 8 interleaved hop-128 sequences (r8x3, rbig
     and rsmall): every frame count from one frame up, several clips, spectrum + fused band power against the oracle / the written
@@ -323,7 +323,7 @@ def test_register_f64_matches_stockham_and_edges(sp, nperseg):
         plan.force_kernel("rsmalld" if nperseg == 1024 else "r8x3d")
 
 
-@pytest.mark.parametrize("nperseg,hop,family", [(256, 64, "rsmall"), (512, 448, "rsmall"), (1024, 256, "r8x3"), (2048, 128, "rbig"),
+@pytest.mark.parametrize("nperseg,hop,family", [(128, 32, "rsmall"), (256, 64, "rsmall"), (512, 448, "rsmall"), (1024, 256, "r8x3"), (2048, 128, "rbig"),
                                                 (4096, 1024, "rbig"), (1024, 256, "stockham")])
 def test_fused_band_power_every_f32_family(sp, nperseg, hop, family):
     """A11 fused into the transform (sg_stft_band_power): the per-frame band sum must equal the sum over the written spectrum's
@@ -349,7 +349,7 @@ def test_fused_band_power_every_f32_family(sp, nperseg, hop, family):
         d_s.download(spec)
         _capi.stream_sync()
         h = nperseg // 2
-        for k_lo, k_hi in [(0, h), (1, 7), (h // 2, h // 2), (h // 2 - 1, h // 2 + 1), (h // 2 + 1, h - 3), (0, 0), (h, h), (65, h - 1)]:
+        for k_lo, k_hi in [(0, h), (1, 7), (h // 2, h // 2), (h // 2 - 1, h // 2 + 1), (h // 2 + 1, h - 3), (0, 0), (h, h), (min(65, h - 2), h - 1)]:
             _capi.check(_capi.lib().sg_memset(C.c_void_p(d_bp.ptr), 0xFF, 5 * nfr * 4, None))
             plan.band_power(d_in.ptr, ns, ns, 5, k_lo, k_hi, d_bp.ptr, nfr)
             bp = np.empty((5, nfr), np.float32)
@@ -634,12 +634,13 @@ def test_argument_errors(sp):
         sp.spectrogram(x.astype(np.complex64), nperseg=64)
 
 
-@pytest.mark.parametrize("n", [256, 512])
-@pytest.mark.parametrize("hop,detrend,mode", [(64, "constant", "psd"), (128, "constant", "psd"), (256, False, "psd"),
-                                              (2, "constant", "magnitude"), (None, "constant", "psd")])
+@pytest.mark.parametrize("n,hop,detrend,mode", [(n, h, d, m) for n in (256, 512) for h, d, m in
+                                                [(64, "constant", "psd"), (128, "constant", "psd"), (256, False, "psd"), (2, "constant", "magnitude"), (None, "constant", "psd")]]
+                         + [(128, 32, "constant", "psd"), (128, 64, "constant", "psd"), (128, 128, False, "psd"), (128, 2, "constant", "magnitude"),
+                            (128, None, "constant", "psd")])
 def test_rsmall_kernel(sp, n, hop, detrend, mode):
-    """Register kernel for nfft 256 / 512 (G = 4 / 2 frames per wave): vs oracle and vs the Stockham kernel, incl. a
-    frame count that is not a multiple of the group size and several clips."""
+    """Register kernel for nfft 128 / 256 / 512 (G = 8 / 4 / 2 frames per wave; 128 since round 4): vs oracle and vs the Stockham kernel,
+    incl. a frame count that is not a multiple of the group size and several clips."""
     from spectro import _capi
     from spectro.signal import plan_for
     from spectro.windows import get_window
@@ -1010,7 +1011,8 @@ def test_rblue_band_power_int16_and_fallbacks(sp, n, hop):
     (3000, 750, "constant", "psd", "hann"), (2080, 1820, "constant", "psd", ("tukey", 0.25)), (2052, 513, False, "magnitude", "hann"),
     (4092, 1024, "constant", "psd", "boxcar"), (4064, 508, False, "psd", "hann"),
     (6000, 1500, "constant", "psd", "hann"), (8160, 7140, "constant", "psd", ("tukey", 0.25)), (4104, 1027, False, "magnitude", "hann"),
-    (8184, 2046, "constant", "psd", "boxcar"), (5120, 640, "constant", "magnitude", "hann")])
+    (8184, 2046, "constant", "psd", "boxcar"), (5120, 640, "constant", "magnitude", "hann"), (8192, 2048, "constant", "psd", "hann"),
+    (8192, 7168, "constant", "psd", ("tukey", 0.25))])
 def test_rbluew_kernel(sp, n, hop, detrend, mode, window):
     """nperseg 2080 ... 8192 that is no power of two (the GUI's spin box runs to 8192 in steps of 32, GUI.py:87-89): the wide register
     chirp-z kernel (stft_rbluew.hip, round 4: two wavefronts per frame up to 4096, four above) against the oracle -- several clips incl.
@@ -1095,7 +1097,7 @@ def test_rbluew_many_frames_band_power_and_int16(sp, n, hop, clips, frames):
     (2044, 512, "constant", "psd", "boxcar"),
     (3000, 750, "constant", "psd", "hann"), (4088, 3577, "constant", "psd", ("tukey", 0.25)), (2056, 515, False, "magnitude", "hann"),
     (6000, 1500, "constant", "psd", "hann"), (8160, 7140, "constant", "psd", ("tukey", 0.25)), (4112, 1029, False, "magnitude", "hann"),
-    (8176, 2044, "constant", "psd", "boxcar")])
+    (8176, 2044, "constant", "psd", "boxcar"), (8192, 7168, "constant", "psd", ("tukey", 0.25)), (8192, 1024, False, "magnitude", "hann")])
 def test_rbluew_f64_kernel(sp, n, hop, detrend, mode, window):
     """The reference's own flow at nperseg 1056 ... 8160 (float64 recordings, SweepManager.py:135-136; the spin box runs to 8192 in steps
     of 32, GUI.py:87-89): the wide double-precision register chirp-z kernel (stft_rbluew_f64.hip, round 4: two / four / eight wavefronts

@@ -84,6 +84,6 @@ def run(R, rep):
 
 
 if __name__ == "__main__":
-    for R in (2, 4, 8):
+    for R in (1, 2, 4, 8):
         rep = {}
         print("R", R, "nfft", 128 * R, "max rel err", run(R, rep), rep)
