@@ -25,7 +25,7 @@ static bool r8x3_ok(const sg_plan& p) {
 }
 
 static bool r8x3d_ok(const sg_plan& p) {
-    return p.dtype == SG_F64 && p.nperseg == p.nfft && (p.nfft == 256 || p.nfft == 512 || p.nfft == 1024) &&
+    return p.dtype == SG_F64 && p.nperseg == p.nfft && (p.nfft == 128 || p.nfft == 256 || p.nfft == 512 || p.nfft == 1024) &&
            (p.detrend == SG_DETREND_NONE || p.detrend == SG_DETREND_CONSTANT) &&
            (p.mode == SG_MODE_PSD || p.mode == SG_MODE_MAGNITUDE);
 }

@@ -1,4 +1,4 @@
-// stft_r8x3_f64.hip -- the register kernels in double precision: nperseg = nfft = 1024 ("r8x3d"), 512 and 256 ("rsmalld").
+// stft_r8x3_f64.hip -- the register kernels in double precision: nperseg = nfft = 1024 ("r8x3d"), 512, 256 and (round 4) 128 ("rsmalld").
 //
 // Why they exist: the reference's default nperseg is 1024 (GUI.py:214, spin box 32...8192) and its recordings arrive as float64
 // (neo magnitudes, SweepManager.py:135-136), and scipy computes in the input's precision (scipy/signal/_spectral_py.py:1976-1981)
@@ -113,6 +113,7 @@ struct R8DParams {
 };
 
 template <int R> __device__ __forceinline__ void radix_first(cd* a);
+template <> __device__ __forceinline__ void radix_first<1>(cd*) {}
 template <> __device__ __forceinline__ void radix_first<2>(cd* a) {
     const cd s = cadd(a[0], a[1]), d = csub(a[0], a[1]);
     a[0] = s; a[1] = d;
@@ -131,7 +132,7 @@ template <int L> __device__ __forceinline__ double group_sum(double v) {     // 
     return v;
 }
 
-// R = nfft/128: 2 (256), 4 (512), 8 (1024).  A wave carries G = 8/R frames per step (stft_rsmall.hip; G = 1 is the r8x3 mapping).
+// R = nfft/128: 1 (128: no pass 1), 2 (256), 4 (512), 8 (1024).  A wave carries G = 8/R frames per step (stft_rsmall.hip; G = 1 is the r8x3 mapping).
 // MODE 0 psd, 1 magnitude, 2 band power: out[clip][frame] = sum of PSD bins [k_lo, k_hi] (A11)
 template <int R, bool DETREND, int MODE>
 __global__ __launch_bounds__(64 * kWaves, kOcc) void stft_reg_f64_kernel(const R8DParams p) {
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(64 * kWaves, kOcc) void stft_reg_f64_kernel(const R
 
     cd w[R], t3[4];
 #if !SG_R8D_TW_LDS
-    cd t1[R - 1], t2[7];
+    cd t1[R > 1 ? R - 1 : 1], t2[7];
 #endif
     const double sq = sqrt(MODE != 1 ? p.scale * 0.5 : p.scale * 0.25);      // PSD scale rides on the window (stft_r8x3.hip)
 #pragma unroll
@@ -337,6 +338,7 @@ bool r8x3_f64_can_run(const sg_plan& p, const StftArgs& a) {
 int launch_r8x3_f64(const sg_plan& p, const StftArgs& a) {
     if (a.n_frames <= 0 || a.n_clips <= 0) return SG_OK;
     switch (p.nfft) {
+        case 128: return launch_r<1>(p, a);
         case 256: return launch_r<2>(p, a);
         case 512: return launch_r<4>(p, a);
         default: return launch_r<8>(p, a);
