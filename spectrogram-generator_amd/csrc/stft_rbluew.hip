@@ -64,7 +64,9 @@ struct WideParams {
 };
 
 // MODE: 0 psd, 1 magnitude, 2 band power (A11)
-template <int W, bool DETREND, int MODE>
+// DIRECT (nperseg 8192, W = 4: mp = 1024 = L / 2): the wave's DFT of mp points is every second bin of ONE zero-padded L-point transform --
+// no chirp, no filter, no second transform; half of that transform's bins are computed for nothing, which is still half the chirp-z work
+template <int W, bool DETREND, int MODE, bool DIRECT>
 __global__ __launch_bounds__((64 * WideCfg<W>::kWaves), 2) void stft_rbluew_kernel(const WideParams p) {
     using C = WideCfg<W>;
     constexpr int T = C::T, R = C::R, kWaves = C::kWaves;
@@ -156,9 +158,14 @@ __global__ __launch_bounds__((64 * WideCfg<W>::kWaves), 2) void stft_rbluew_kern
 #pragma unroll
         for (int a = 0; a < R; ++a) {
             if (a < C::kRows) {
-                const float2 wn = lds_get(win + 64 * a), c = lds_get(chirp + 64 * a);
+                const float2 wn = lds_get(win + 64 * a);
                 const float x0 = (nxt[a].x - mean) * wn.x, x1 = (nxt[a].y - mean) * wn.y;
-                d[a % T][a / T] = make_float2(fmaf(x0, c.x, -x1 * c.y), fmaf(x0, c.y, x1 * c.x));
+                if (DIRECT) {
+                    d[a % T][a / T] = make_float2(x0, x1);
+                } else {
+                    const float2 c = lds_get(chirp + 64 * a);
+                    d[a % T][a / T] = make_float2(fmaf(x0, c.x, -x1 * c.y), fmaf(x0, c.y, x1 * c.x));
+                }
             } else {
                 d[a % T][a / T] = make_float2(0.f, 0.f);
             }
@@ -166,6 +173,7 @@ __global__ __launch_bounds__((64 * WideCfg<W>::kWaves), 2) void stft_rbluew_kern
         load_frame(clip_n, f_n, nxt);                        // the group's last frame fetches itself again
         cfft_wave<T>(d, e, fl);
         // ---- Y = conj(A * B) -----------------------------------------------------------------------------------------------------------
+        if (!DIRECT) {
 #pragma unroll
         for (int c = 0; c < R; c += 2) {
             const v4f fb = lds_get2(lds + C::kFilt + (c >> 1) * 128 + 2 * lane);
@@ -175,7 +183,23 @@ __global__ __launch_bounds__((64 * WideCfg<W>::kWaves), 2) void stft_rbluew_kern
             d[(c + 1) % T][(c + 1) / T] = make_float2(y1.x, -y1.y);
         }
         cfft_wave<T>(d, e, fl);                              // e = V; the convolution is conj(V) (1 / L is in B)
+        }
         // ---- G_w[k0] = W_N2^(w k0) * c[k0] * conj(V[k0]) -> this wave's slab ---------------------------------------------------------------
+        if (DIRECT) {                                        // F_w[k] = A[2k]: bin lane + 64 c of the transform is k = lane / 2 + 32 c for even lanes
+#pragma unroll
+            for (int c = 0; c < R; ++c) {
+                float2 z = e[c % T][c / T];
+                const int k = (lane >> 1) + 32 * c;
+                if (w != 0) {                                // wave-uniform
+                    const float2 t = lds_get(lds + C::kCtw + k);
+                    float2 pw = t;
+                    if (w >= 2) pw = cmul(t, t);
+                    if (w == 3) pw = cmul(pw, t);
+                    z = cmul(z, pw);
+                }
+                if ((lane & 1) == 0) lds_put(slab + k, z);
+            }
+        } else {
 #pragma unroll
         for (int c = 0; c < C::kRows; ++c) {
             const float2 ch = lds_get(chirp + 64 * c);
@@ -189,6 +213,7 @@ __global__ __launch_bounds__((64 * WideCfg<W>::kWaves), 2) void stft_rbluew_kern
                 z = cmul(z, pw);
             }
             lds_put(slab + lane + 64 * c, z);
+        }
         }
         if (DETREND) {                                       // the next frame's samples have arrived by now
             const float s = part_sum(nxt);
@@ -259,12 +284,12 @@ __global__ __launch_bounds__((64 * WideCfg<W>::kWaves), 2) void stft_rbluew_kern
     }
 }
 
-template <int W, bool DETREND>
+template <int W, bool DETREND, bool DIRECT>
 int launch_wd(const WideParams& prm, hipStream_t s, int mode, bool band, int n_cu) {
     using C = WideCfg<W>;
-    auto k0 = stft_rbluew_kernel<W, DETREND, 0>;
-    auto k1 = stft_rbluew_kernel<W, DETREND, 1>;
-    auto k2 = stft_rbluew_kernel<W, DETREND, 2>;
+    auto k0 = stft_rbluew_kernel<W, DETREND, 0, DIRECT>;
+    auto k1 = stft_rbluew_kernel<W, DETREND, 1, DIRECT>;
+    auto k2 = stft_rbluew_kernel<W, DETREND, 2, DIRECT>;
     auto kern = band ? k2 : mode == SG_MODE_PSD ? k0 : k1;
     WideParams p = prm;
     int64_t n_groups = static_cast<int64_t>(n_cu) * C::kGroups;                 // one workgroup per CU (its tables fill the LDS)
@@ -295,8 +320,11 @@ int launch_w(const sg_plan& p, const StftArgs& a) {
     prm.scale = static_cast<float>(p.scale);
     prm.k_lo = a.k_lo; prm.k_hi = a.k_hi;
     const bool band = a.band_mode != 0;                    // run_stft has checked: psd plan, 0 <= k_lo <= k_hi < n_bins
-    return p.detrend == SG_DETREND_CONSTANT ? launch_wd<W, true>(prm, a.stream, p.mode, band, p.n_cu)
-                                            : launch_wd<W, false>(prm, a.stream, p.mode, band, p.n_cu);
+    if (W == 4 && p.nfft == 8192)                          // mp = 1024 = L / 2: no chirp
+        return p.detrend == SG_DETREND_CONSTANT ? launch_wd<W, true, (W == 4)>(prm, a.stream, p.mode, band, p.n_cu)
+                                                : launch_wd<W, false, (W == 4)>(prm, a.stream, p.mode, band, p.n_cu);
+    return p.detrend == SG_DETREND_CONSTANT ? launch_wd<W, true, false>(prm, a.stream, p.mode, band, p.n_cu)
+                                            : launch_wd<W, false, false>(prm, a.stream, p.mode, band, p.n_cu);
 }
 
 template <int W>

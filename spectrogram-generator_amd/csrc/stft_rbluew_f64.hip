@@ -62,7 +62,8 @@ struct WideDParams {
 };
 
 // MODE: 0 psd, 1 magnitude, 2 band power (A11)
-template <int W, bool DETREND, int MODE>
+// DIRECT (nperseg 8192, W = 8: mp = 512 = L / 2): the wave's DFT of mp points is every second bin of ONE zero-padded L-point transform (stft_rbluew.hip)
+template <int W, bool DETREND, int MODE, bool DIRECT>
 __global__ __launch_bounds__((64 * WideDCfg<W>::kWaves), 2) void stft_rbluew_f64_kernel(const WideDParams p) {
     using C = WideDCfg<W>;
     constexpr int T = C::T, R = C::R, kWaves = C::kWaves;
@@ -166,34 +167,39 @@ __global__ __launch_bounds__((64 * WideDCfg<W>::kWaves), 2) void stft_rbluew_f64
 #pragma unroll
         for (int a = 0; a < R; ++a) {
             if (a < C::kRows) {
-                const cd c = tab_l.get(C::kChirp + 64 * a);
-                d[a % T][a / T] = cmul(cd{(nxt[a].x - mean) * win[a].x, (nxt[a].y - mean) * win[a].y}, c);
+                const cd xw = {(nxt[a].x - mean) * win[a].x, (nxt[a].y - mean) * win[a].y};
+                d[a % T][a / T] = DIRECT ? xw : cmul(xw, tab_l.get(C::kChirp + 64 * a));
             } else {
                 d[a % T][a / T] = cd{0.0, 0.0};
             }
         }
         cfft_wave_f64<T>(d, e, tab, C::kTw1, C::kTw2, sl, lane);
+        if (!DIRECT) {
 #pragma unroll
-        for (int c = 0; c < R; ++c) {                        // Y = conj(A * B)
-            const cd y = cmul(e[c % T][c / T], tab_l.get(C::kFilt + 64 * c));
-            d[c % T][c / T] = cd{y.x, -y.y};
+            for (int c = 0; c < R; ++c) {                    // Y = conj(A * B)
+                const cd y = cmul(e[c % T][c / T], tab_l.get(C::kFilt + 64 * c));
+                d[c % T][c / T] = cd{y.x, -y.y};
+            }
+            cfft_wave_f64<T>(d, e, tab, C::kTw1, C::kTw2, sl, lane);         // e = V; the convolution is conj(V) (1 / L is in B)
         }
-        cfft_wave_f64<T>(d, e, tab, C::kTw1, C::kTw2, sl, lane);             // e = V; the convolution is conj(V) (1 / L is in B)
         if (C::kPrefetch) load_frame(clip_n, f_n, nxt);      // prefetch, issued where the register file has room for it (the group's last frame fetches itself again)
         // ---- G_w[k0] = W_N2^(w k0) * c[k0] * conj(V[k0]) -> this wave's slab ----
 #pragma unroll
-        for (int c = 0; c < C::kRows; ++c) {
-            const cd ch = tab_l.get(C::kChirp + 64 * c), v = e[c % T][c / T];
-            cd z = cmul(cd{v.x, -v.y}, ch);
+        for (int c = 0; c < (DIRECT ? R : C::kRows); ++c) {
+            // DIRECT: F_w[k] = A[2k]: bin lane + 64 c of the transform is k = lane / 2 + 32 c for even lanes
+            const int k = DIRECT ? (lane >> 1) + 32 * c : lane + 64 * c;
+            const cd v = e[c % T][c / T];
+            cd z = DIRECT ? v : cmul(cd{v.x, -v.y}, tab_l.get(C::kChirp + 64 * c));
             if (w != 0) {                                    // wave-uniform: t^w by squaring
-                const cd t = tab_l.get(C::kCtw + 64 * c);
+                const cd t = DIRECT ? tab.get(C::kCtw + k) : tab_l.get(C::kCtw + 64 * c);
                 const cd t2 = cmul(t, t);
                 cd pw = (w & 1) ? t : cd{1.0, 0.0};
                 if (w & 2) pw = (w & 1) ? cmul(pw, t2) : t2;
                 if (W > 4 && (w & 4)) { const cd t4 = cmul(t2, t2); pw = (w & 3) ? cmul(pw, t4) : t4; }
                 z = cmul(z, pw);
             }
-            sl_l.put(64 * c, z);
+            if (!DIRECT) sl_l.put(64 * c, z);
+            else if ((lane & 1) == 0) sl.put(k, z);
         }
         __syncthreads();                                     // (1) every G_w of the workgroup is in LDS
         // ---- Z[k0 + w mp] = sum_v W_W^(v w) G_v[k0] ----
@@ -279,12 +285,12 @@ __global__ __launch_bounds__((64 * WideDCfg<W>::kWaves), 2) void stft_rbluew_f64
     }
 }
 
-template <int W, bool DETREND>
+template <int W, bool DETREND, bool DIRECT>
 int launch_wd(const WideDParams& prm, hipStream_t s, int mode, bool band, int n_cu) {
     using C = WideDCfg<W>;
-    auto k0 = stft_rbluew_f64_kernel<W, DETREND, 0>;
-    auto k1 = stft_rbluew_f64_kernel<W, DETREND, 1>;
-    auto k2 = stft_rbluew_f64_kernel<W, DETREND, 2>;
+    auto k0 = stft_rbluew_f64_kernel<W, DETREND, 0, DIRECT>;
+    auto k1 = stft_rbluew_f64_kernel<W, DETREND, 1, DIRECT>;
+    auto k2 = stft_rbluew_f64_kernel<W, DETREND, 2, DIRECT>;
     auto kern = band ? k2 : mode == SG_MODE_PSD ? k0 : k1;
     WideDParams p = prm;
     int64_t n_groups = static_cast<int64_t>(n_cu) * C::kGroups;                 // one workgroup per CU
@@ -315,8 +321,11 @@ int launch_w(const sg_plan& p, const StftArgs& a) {
     prm.scale = p.scale;
     prm.k_lo = a.k_lo; prm.k_hi = a.k_hi;
     const bool band = a.band_mode != 0;                    // run_stft has checked: psd plan, 0 <= k_lo <= k_hi < n_bins
-    return p.detrend == SG_DETREND_CONSTANT ? launch_wd<W, true>(prm, a.stream, p.mode, band, p.n_cu)
-                                            : launch_wd<W, false>(prm, a.stream, p.mode, band, p.n_cu);
+    if (W == 8 && p.nfft == 8192)                          // mp = 512 = L / 2: no chirp
+        return p.detrend == SG_DETREND_CONSTANT ? launch_wd<W, true, (W == 8)>(prm, a.stream, p.mode, band, p.n_cu)
+                                                : launch_wd<W, false, (W == 8)>(prm, a.stream, p.mode, band, p.n_cu);
+    return p.detrend == SG_DETREND_CONSTANT ? launch_wd<W, true, false>(prm, a.stream, p.mode, band, p.n_cu)
+                                            : launch_wd<W, false, false>(prm, a.stream, p.mode, band, p.n_cu);
 }
 
 void host_fft_ld(std::vector<long double>& re, std::vector<long double>& im) {      // radix-2, once per plan, for the filter spectrum
