@@ -5,7 +5,7 @@ CC      ?= gcc
 PKG     := spectrogram-generator_amd
 CSRC    := $(PKG)/csrc
 LIBDIR  := $(PKG)/lib
-SOURCES := host_shim spectro_api stft_r8x3 stft_r8x3_f64 stft_rsmall stft_rbig stft_rbig_f64 stft_stockham stft_bluestein stft_rblue stft_rblue_f64 stft_rbluew stft_rbluew_f64 epilogue mel stft_mel_fused
+SOURCES := host_shim spectro_api stft_r8x3 stft_r8x3_f64 stft_rsmall stft_rbig stft_rbig_f64 stft_stockham stft_bluestein stft_rblue stft_rblue_f64 stft_rbluew stft_rbluew_f64 stft_rtiny epilogue mel stft_mel_fused
 OBJS    := $(SOURCES:%=$(LIBDIR)/%.o)
 HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -fno-gpu-rdc -Wall -Wno-unused-function -Wno-unused-result
 # register-FFT kernels: gfx950 issues v_pk_*_f32 at half rate, so no SLP packing (see build.py)

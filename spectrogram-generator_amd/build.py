@@ -18,7 +18,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libspectro.so")
-SOURCES = ["host_shim.cpp", "spectro_api.hip", "stft_r8x3.hip", "stft_r8x3_f64.hip", "stft_rsmall.hip", "stft_rbig.hip", "stft_rbig_f64.hip", "stft_stockham.hip", "stft_bluestein.hip", "stft_rblue.hip", "stft_rblue_f64.hip", "stft_rbluew.hip", "stft_rbluew_f64.hip", "epilogue.hip", "mel.hip", "stft_mel_fused.hip"]
+SOURCES = ["host_shim.cpp", "spectro_api.hip", "stft_r8x3.hip", "stft_r8x3_f64.hip", "stft_rsmall.hip", "stft_rbig.hip", "stft_rbig_f64.hip", "stft_stockham.hip", "stft_bluestein.hip", "stft_rblue.hip", "stft_rblue_f64.hip", "stft_rbluew.hip", "stft_rbluew_f64.hip", "stft_rtiny.hip", "epilogue.hip", "mel.hip", "stft_mel_fused.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-fno-gpu-rdc",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 if os.environ.get("SG_TUNING") == "1":          # the launch-time tuning variables of the A/B tools (csrc/spectro_internal.h: SG_TUNE_ENV); never in the product build

@@ -36,6 +36,13 @@ static bool rsmall_ok(const sg_plan& p) {
            (p.mode == SG_MODE_PSD || p.mode == SG_MODE_MAGNITUDE);
 }
 
+// nperseg 32 / 64, f32 and f64: the quad-DPP register kernel (stft_rtiny.hip)
+static bool rtiny_ok(const sg_plan& p) {
+    return (p.dtype == SG_F32 || p.dtype == SG_F64) && p.nperseg == p.nfft && (p.nfft == 32 || p.nfft == 64) &&
+           (p.detrend == SG_DETREND_NONE || p.detrend == SG_DETREND_CONSTANT) &&
+           (p.mode == SG_MODE_PSD || p.mode == SG_MODE_MAGNITUDE);
+}
+
 static bool rbig_ok(const sg_plan& p) {
     return p.dtype == SG_F32 && p.nperseg == p.nfft && (p.nfft == 2048 || p.nfft == 4096) &&
            (p.detrend == SG_DETREND_NONE || p.detrend == SG_DETREND_CONSTANT) &&
@@ -226,7 +233,7 @@ static int run_stft(const sg_plan* plan, StftArgs& a) {
         if (plan->mode != SG_MODE_PSD) { set_error("band power needs a psd plan"); return SG_ERR_ARG; }
         if (a.k_lo < 0 || a.k_hi >= nbins || a.k_lo > a.k_hi) { set_error("bad band [%d,%d] of %d bins", a.k_lo, a.k_hi, nbins); return SG_ERR_ARG; }
     }
-    if (a.in_i16 && (plan->kernel == Kernel::RSMALL || plan->kernel == Kernel::RBIG) && plan->hop % 2 == 0 &&
+    if (a.in_i16 && (plan->kernel == Kernel::RSMALL || plan->kernel == Kernel::RBIG || (plan->kernel == Kernel::RTINY && plan->dtype == SG_F32)) && plan->hop % 2 == 0 &&
         (a.clip_stride % 2 == 0 || a.n_clips == 1) && static_cast<int64_t>(a.n_clips) * a.n_samples >= (1 << 18))
         return run_converted(plan, a);
     if ((plan->kernel == Kernel::RBLUE || plan->kernel == Kernel::RBLUEW) && a.in_i16) return run_converted(plan, a);     // no chirp-z kernel loads int16
@@ -236,6 +243,7 @@ static int run_stft(const sg_plan* plan, StftArgs& a) {
         case Kernel::RSMALL: return rsmall_can_run(*plan, a) ? launch_rsmall(*plan, a) : launch_stockham(*plan, a);
         case Kernel::RBIG: return rbig_can_run(*plan, a) ? launch_rbig(*plan, a) : launch_stockham(*plan, a);
         case Kernel::RBIGD: return rbig_f64_can_run(*plan, a) ? launch_rbig_f64(*plan, a) : launch_stockham(*plan, a);
+        case Kernel::RTINY: return rtiny_can_run(*plan, a) ? launch_rtiny(*plan, a) : launch_stockham(*plan, a);
         case Kernel::STOCKHAM: return launch_stockham(*plan, a);
         case Kernel::BLUESTEIN: return launch_bluestein(*plan, a);
         // odd hops / unaligned clips, GUI-sized int16 calls: the LDS chirp-z kernel (its tables are built with the plan); it writes full spectra only
@@ -399,6 +407,9 @@ int sg_plan_create(sg_plan** plan, int nperseg, int nfft, int hop, const double*
         } else if (rsmall_ok(*p)) {
             p->kernel = Kernel::RSMALL;
             rc = build_rsmall_tables(*p);
+        } else if (rtiny_ok(*p)) {
+            p->kernel = Kernel::RTINY;
+            rc = build_rtiny_tables(*p);
         } else if (rbig_ok(*p)) {
             p->kernel = Kernel::RBIG;
             rc = build_rbig_tables(*p);
@@ -466,6 +477,7 @@ const char* sg_plan_kernel(const sg_plan* plan) {
         case Kernel::BLUESTEIN: return "bluestein";
         case Kernel::RBLUE: return "rblue";
         case Kernel::RBLUED: return "rblued";
+        case Kernel::RTINY: return plan->dtype == SG_F64 ? "rtinyd" : "rtiny";
         case Kernel::RBLUEW: return "rbluew";
         case Kernel::RBLUEWD: return "rbluewd";
     }
@@ -518,6 +530,12 @@ int sg_plan_force_kernel(sg_plan* plan, const char* name) {
         if (!rblue_ok(*plan)) { set_error("plan cannot run on rblue"); return SG_ERR_UNSUPPORTED; }
         if (!plan->rb_wc_dev) { set_error("rblue tables are built with the plan only"); return SG_ERR_UNSUPPORTED; }
         plan->kernel = Kernel::RBLUE;
+        return SG_OK;
+    }
+    if (!strcmp(name, "rtiny") || !strcmp(name, "rtinyd")) {
+        if (!rtiny_ok(*plan) || (plan->dtype == SG_F64) != (name[5] == 'd')) { set_error("plan cannot run on %s", name); return SG_ERR_UNSUPPORTED; }
+        if (!plan->r8_tw_dev) { if (int rc = build_rtiny_tables(*plan)) return rc; }
+        plan->kernel = Kernel::RTINY;
         return SG_OK;
     }
     if (!strcmp(name, "rbluewd")) {

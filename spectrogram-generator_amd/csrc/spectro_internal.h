@@ -30,7 +30,7 @@ int hip_fail(hipError_t e, const char* what);   // records message, returns SG_E
 #define SG_TUNE_ENV(name) (static_cast<const char*>(nullptr))
 #endif
 
-enum class Kernel { R8X3, R8X3D, RSMALL, RBIG, RBIGD, STOCKHAM, BLUESTEIN, RBLUE, RBLUED, RBLUEW, RBLUEWD };
+enum class Kernel { R8X3, R8X3D, RSMALL, RBIG, RBIGD, STOCKHAM, BLUESTEIN, RBLUE, RBLUED, RBLUEW, RBLUEWD, RTINY };
 
 }  // namespace sg
 
@@ -105,6 +105,8 @@ int launch_rbluew(const sg_plan& p, const StftArgs& a);
 bool rbluew_can_run(const sg_plan& p, const StftArgs& a);
 int rbluew_size(int nfft);
 int launch_rbluew_f64(const sg_plan& p, const StftArgs& a);
+int launch_rtiny(const sg_plan& p, const StftArgs& a);
+bool rtiny_can_run(const sg_plan& p, const StftArgs& a);
 bool rbluew_f64_can_run(const sg_plan& p, const StftArgs& a);
 int rbluew_f64_size(int nfft);
 bool rblue_f64_can_run(const sg_plan& p, const StftArgs& a);
@@ -119,6 +121,7 @@ int build_rblue_tables(sg_plan& p, const std::vector<double>& window);
 int build_rblue_f64_tables(sg_plan& p, const std::vector<double>& window);
 int build_rbluew_tables(sg_plan& p, const std::vector<double>& window);
 int build_rbluew_f64_tables(sg_plan& p, const std::vector<double>& window);
+int build_rtiny_tables(sg_plan& p);
 void host_fft_pow2(std::vector<double>& re, std::vector<double>& im);     // in place, forward, radix 2 (stft_rblue.hip)
 
 }  // namespace sg

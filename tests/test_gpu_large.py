@@ -75,6 +75,7 @@ CASES = [  # dtype, nperseg, hop, window, forced family, expected family
     ("f32", 1000, 250, "hann", "bluestein", "bluestein"),
     ("f64", 1024, 256, ("tukey", 0.25), None, "r8x3d"),
     ("f64", 1000, 250, "hann", None, "rblued"),
+    ("f32", 64, 16, "hann", None, "rtiny"),
     ("f32", 4000, 1000, "hann", None, "rbluew"),
     ("f64", 4000, 1000, "hann", None, "rbluewd"),
 ]

@@ -103,7 +103,7 @@ def test_r8x3_variants(sp, hop, detrend, mode):
     assert_spec_close(s, so, time_axis=-1)
 
 
-@pytest.mark.parametrize("nperseg,hop", [(128, 32), (256, 64), (512, 128), (512, 127), (1024, 256), (2048, 128), (4096, 1024), (2048, 333), (1000, 250), (4000, 1000)])
+@pytest.mark.parametrize("nperseg,hop", [(32, 8), (64, 16), (128, 32), (256, 64), (512, 128), (512, 127), (1024, 256), (2048, 128), (4096, 1024), (2048, 333), (1000, 250), (4000, 1000)])
 def test_int16_pcm_batches_every_family(sp, nperseg, hop):
     """int16 PCM (16-bit WAV): the result must equal the float call on the same values BIT FOR BIT in every kernel family -- r8x3
     and the LDS kernel load int16 themselves, rsmall / rbig batches convert once into a stream-ordered workspace
@@ -661,6 +661,80 @@ def test_rsmall_kernel(sp, n, hop, detrend, mode):
     f2, t2, s2 = sp.spectrogram(y, fs=48000.0, nperseg=n, window="hann", noverlap=n - 33)
     _, _, so2 = orc.spectrogram(y, fs=48000.0, nperseg=n, window="hann", noverlap=n - 33)
     assert_spec_close(s2, so2, time_axis=-1)
+
+
+@pytest.mark.parametrize("dt", ["float32", "float64"])
+@pytest.mark.parametrize("n,hop,detrend,mode", [(64, 16, "constant", "psd"), (64, 2, "constant", "magnitude"), (64, 64, False, "psd"), (64, None, "constant", "psd"),
+                                                (32, 8, "constant", "psd"), (32, 2, False, "magnitude"), (32, 32, "constant", "psd"), (32, None, "constant", "psd")])
+def test_rtiny_kernel(sp, dt, n, hop, detrend, mode):
+    """The smallest sizes of the spin box (GUI.py:87-89: 32, 64): the quad-DPP register kernel (stft_rtiny.hip, round 4: 16 / 32 frames per
+    wave, no LDS in the transform) in f32 and f64 -- vs the oracle and vs the Stockham kernel of the same plan, frame counts that are no
+    multiple of the group size, several clips incl. all-zero and constant ones, the fused band power, int16 and the odd-hop fallback."""
+    from spectro import _capi
+    from spectro.signal import plan_for
+    from spectro.windows import get_window
+    hop = n - n // 8 if hop is None else hop
+    rng = np.random.default_rng(n + hop)
+    frames = 83 if hop > 2 else 301
+    N = n + hop * (frames - 1) + (2 if hop > 2 else 0)       # (even: clips at an even stride)
+    x = (rng.standard_normal((5, N)) * 0.4 + 1.5).astype(dt)
+    x[2] = 0.0
+    x[3] = -7.5
+    kw = dict(fs=500.0, nperseg=n, window=("tukey", 0.25), noverlap=n - hop, detrend=detrend, mode=mode)
+    code = _capi.F32 if dt == "float32" else _capi.F64
+    family = "rtiny" if dt == "float32" else "rtinyd"
+    plan = plan_for(get_window(("tukey", 0.25), n), n, n, hop, _capi.DETREND[detrend], 500.0, 0, _capi.MODE[mode], code)
+    assert plan.kernel == family
+    f, t, s = sp.spectrogram(x, **kw)
+    fo, to, so = orc.spectrogram(x, **kw)
+    np.testing.assert_array_equal(f, fo)
+    np.testing.assert_array_equal(t, to)
+    assert s.shape == so.shape == (5, n // 2 + 1, frames) and s.dtype == so.dtype
+    keep = [0, 1, 4] if detrend else [0, 1, 3, 4]
+    if dt == "float64":
+        _check(s[keep], so[keep], np.float64)
+    else:
+        assert_spec_close(s[keep], so[keep], time_axis=-1, bin_floor=1e-3 if mode == "psd" else 1e-3 ** 0.5)
+    assert np.all(s[2] == 0.0)
+    if detrend:
+        assert np.all(s[3] == 0.0)                           # the mean of a constant is exact for a power-of-two n
+    plan.force_kernel("stockham")
+    try:
+        _, _, s_lds = sp.spectrogram(x, **kw)
+    finally:
+        plan.force_kernel(family)
+    if dt == "float64":
+        _check(s[keep], s_lds[keep], np.float64)
+    else:
+        assert_spec_close(s[keep], s_lds[keep], time_axis=-1, bin_floor=1e-3 if mode == "psd" else 1e-3 ** 0.5)
+    if mode == "psd":                                        # fused band power == the sum over the written bins
+        isz = np.dtype(dt).itemsize
+        d_in, d_bp = _capi.DeviceBuffer(x.nbytes), _capi.DeviceBuffer(5 * frames * isz)
+        d_in.upload(np.ascontiguousarray(x))
+        h = n // 2
+        spec = np.moveaxis(s, -1, -2).astype(np.float64)
+        for k_lo, k_hi in [(0, h), (1, 7), (h, h), (0, 0), (h // 2, h - 1), (7, 9)]:
+            plan.band_power(d_in.ptr, N, N, 5, k_lo, k_hi, d_bp.ptr, frames)
+            bp = np.empty((5, frames), dt)
+            d_bp.download(bp)
+            _capi.stream_sync()
+            ref = spec[:, :, k_lo:k_hi + 1].sum(-1)
+            assert np.all(np.abs(bp - ref) <= (2e-6 if dt == "float32" else 1e-12) * spec.sum(-1) + 1e-300), (k_lo, k_hi)
+        d_in.free(); d_bp.free()
+    # a clip that starts on an odd sample (the register kernel needs aligned pairs) and an odd hop: the Stockham kernel of the same plan
+    y = np.ascontiguousarray(x[0, 1:])
+    for kw2 in (kw, dict(kw, noverlap=n - 3)):
+        _, _, s2 = sp.spectrogram(y, **kw2)
+        _, _, so2 = orc.spectrogram(y, **kw2)
+        if dt == "float64":
+            _check(s2, so2, np.float64)
+        else:
+            assert_spec_close(s2, so2, time_axis=-1, bin_floor=1e-3 if mode == "psd" else 1e-3 ** 0.5)
+    if dt == "float32":
+        xi = np.round(x[:, :n + hop * 40] * 800).astype(np.int16)
+        _, _, s_i = sp.spectrogram(xi, **kw)                 # (a GUI-sized int16 call: the Stockham kernel loads int16 itself; batches are
+        _, _, so_i = orc.spectrogram(xi, **kw)               #  converted on the device and run this kernel: test_int16_pcm_batches_every_family)
+        assert_spec_close(s_i[keep], so_i[keep], time_axis=-1, bin_floor=1e-3 if mode == "psd" else 1e-3 ** 0.5)
 
 
 @pytest.mark.parametrize("n", [2048, 4096])
