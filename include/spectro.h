@@ -44,7 +44,7 @@ extern "C" {
 
 #define SG_VERSION 103 /* 0.1.1: sg_stft_mel takes weights_n_bins; sg_stft_db, sg_db_rescale, sg_colormap_db,
                           * sg_band_features_batch, sg_device_pci_bus_id added; 0.1.2: sg_convert_i16;
-                          * 0.1.3: "rblue" plans (even non-power-of-two nperseg <= 2048), sg_stft_mel's log_scale is a flags word (SG_MEL_*),
+                          * 0.1.3: "rblue" / "rbluew" / "rtiny" plans (every nperseg the reference's spin box produces runs a register kernel), sg_stft_mel's log_scale is a flags word (SG_MEL_*),
                           * no environment variable is read on a launch path */
 
 typedef enum sg_status {
@@ -126,8 +126,10 @@ int sg_plan_n_frames(const sg_plan* plan, int64_t n_samples, int64_t* n_frames);
 int sg_plan_n_bins(const sg_plan* plan, int* n_bins);
 /* the scale factor the kernels multiply |X|^2 with (as double) */
 int sg_plan_scale(const sg_plan* plan, double* scale);
-/* name of the kernel family the plan dispatches to: "r8x3", "r8x3d" / "rsmalld" (f64 nperseg = nfft = 1024 / 256, 512), "rsmall", "rbig", "rbigd",
- * "rblue" / "rblued" (f32 / f64, even nperseg = nfft <= 2048 / 1024 that is no power of two: register chirp-z), "stockham", "bluestein" */
+/* name of the kernel family the plan dispatches to: "r8x3", "r8x3d" / "rsmalld" (f64 nperseg = nfft = 1024 / 128, 256, 512), "rsmall" (128, 256, 512),
+ * "rbig", "rbigd", "rtiny" / "rtinyd" (32, 64), "rblue" / "rblued" (f32 / f64, even nperseg = nfft <= 2048 / 1024 that is no power of two: register
+ * chirp-z), "rbluew" / "rbluewd" (the same up to 8192, nperseg a multiple of 4 / 8 / 16: two to eight wavefronts per frame; 8192 itself too),
+ * "stockham", "bluestein" */
 const char* sg_plan_kernel(const sg_plan* plan);
 /* Tests / benchmarks: route the plan to another family that can run it ("stockham" for an
  * r8x3 plan).  SG_ERR_UNSUPPORTED if that family cannot run this plan. */
@@ -163,7 +165,7 @@ int sg_convert_i16(const int16_t* src_dev, float* dst_dev, int64_t n, void* stre
  * Same framing/FFT but the spectrum never reaches HBM: per frame only
  * p[frame] = sum_{k in [k_lo, k_hi]} Sxx[k, frame] is written (A11 band sum,
  * PlotEngine.py:238-239).  band_out_dev: [n_clips][n_frames] of the plan's dtype.
- * Needs a psd plan; fused in every register family (f32 256...4096 and "rblue", f64 256...4096) and in the LDS kernel;
+ * Needs a psd plan; fused in every register family (f32 and f64, every power of two 32...4096 and the chirp-z families) and in the LDS kernel;
  * SG_ERR_UNSUPPORTED on an LDS chirp-z ("bluestein") plan (use sg_stft + sg_band_sum there).
  */
 int sg_stft_band_power(const sg_plan* plan, const void* x_dev, int64_t n_samples,
