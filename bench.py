@@ -616,6 +616,23 @@ def time_secondary(_capi, get_window, xs, dev, stream):
         pn.close()
         del o2
     out["nperseg_4000"] = np2w
+    # ... and the reference's OWN call on its own dtype across the spin box (float64 recordings, SweepManager.py:135-136; Tukey, hop n - n // 8,
+    # PlotEngine.py:113): 32 clips, one kernel family per size
+    ref64 = {}
+    c64 = min(32, n_clips)
+    x64 = xs[0][:c64].double()
+    for n64 in (64, 1024, 4000, 8192):
+        hop64, nb64 = n64 - n64 // 8, n64 // 2 + 1
+        pn = _capi.Plan(n64, n64, hop64, get_window(("tukey", 0.25), n64), _capi.DETREND["constant"], FS, _capi.SCALING["density"], _capi.MODE["psd"], _capi.F64)
+        nf = pn.n_frames(N_SAMPLES)
+        o2 = [torch.empty((c64, nf, nb64), device=dev, dtype=torch.float64) for _ in range(2)]
+        us = timed(lambda i: pn.stft(x64.data_ptr(), N_SAMPLES, N_SAMPLES, c64, o2[i % 2].data_ptr(), nf * nb64, stream=stream), 16, settle_s=0.05, budget_s=0.0)
+        ref64[f"nperseg_{n64}"] = {"kernel": pn.kernel, "hop": hop64, "clips": c64, "frames": c64 * nf, "us": us, "frames_per_s": c64 * nf / us * 1e6,
+                                   "bytes_per_frame": (hop64 + nb64) * 8, "frac_of_hbm_peak": c64 * nf * (hop64 + nb64) * 8 / us / 1e3 / HBM_PEAK_GBS}
+        pn.close()
+        del o2
+    del x64
+    out["f64_reference_call"] = ref64
 
     # ---- cfg5: streaming 8 ch x 96 kHz, n_fft 4096 hop 1024, 4096-sample chunks, synchronous feed() host to host (PCIe inclusive)
     st = StreamingSTFT(8, 96000.0, 4096, 1024, window="hann")

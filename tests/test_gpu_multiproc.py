@@ -419,3 +419,4 @@ def test_bench_line_carries_the_secondary_configs():
     assert s["cfg5_streaming"]["realtime_factor"] > 50 and s["cfg5_streaming"]["chunk_ms_p50"] <= s["cfg5_streaming"]["chunk_ms_p99"]
     assert s["nperseg_1000"]["hop_250"]["kernel"] == "rblue" and s["nperseg_1000"]["hop_875"]["kernel"] == "rblue"
     assert s["nperseg_4000"]["hop_1000"]["kernel"] == "rbluew" and s["nperseg_4000"]["hop_3500"]["kernel"] == "rbluew"
+    assert [s["f64_reference_call"][f"nperseg_{n}"]["kernel"] for n in (64, 1024, 4000, 8192)] == ["rtinyd", "r8x3d", "rbluewd", "rbluewd"]
