@@ -833,8 +833,8 @@ def test_random_shapes_property(sp):
     from spectro.signal import plan_for
     from spectro.windows import get_window
     from spectro import _capi
-    for it in range(60):
-        nper = int(rng.choice([8, 32, 33, 64, 96, 100, 128, 255, 256, 500, 512, 1000, 1024, 1536, 2048, 4096]))
+    for it in range(90):
+        nper = int(rng.choice([8, 32, 33, 64, 96, 100, 128, 255, 256, 500, 512, 1000, 1024, 1536, 2048, 4096, 3008, 8192]))
         hop = int(rng.integers(1, nper + 1)) if rng.random() < 0.7 else nper - nper // 8
         hop = max(1, hop)
         n_frames_target = int(rng.integers(1, 40))
@@ -872,6 +872,7 @@ def test_random_shapes_property(sp):
                          _capi.F32 if dt == np.float32 else _capi.F64)
             families.add(p.kernel)
     assert {"r8x3", "rsmall", "rbig", "rblue", "stockham", "bluestein"} <= families, families
+    assert families & {"rtiny", "rtinyd"} and families & {"rbluew", "rbluewd"}, families      # (round 4: the edges of the spin box)
 
 
 def test_abi_argument_errors(sp):
