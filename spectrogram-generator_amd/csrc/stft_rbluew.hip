@@ -15,6 +15,7 @@
 // wave's samples: each wave sums the samples it has PREFETCHED for the next frame and the partial sums travel with G, so the mean costs
 // no barrier of its own.  Four workgroup barriers per frame; a workgroup = 8 waves = 4 (W = 2) or 2 (W = 4) frame groups in lockstep,
 // tables once per workgroup in LDS (145 / 161 KB), one workgroup per CU, two waves per SIMD.
+// nperseg 8192 itself runs here too, without the chirp: see WideCfg<W, EX>.
 // Algorithmic HBM bytes per frame: hop*4 + (n/2+1)*4.
 #include "spectro_internal.h"
 #include "cfft_wave.h"
@@ -27,26 +28,31 @@ namespace {
 
 using namespace wavefft;
 
-template <int W> struct WideCfg {
+// EX ("exact", nperseg 8192 on W = 2 waves): mp = 2048 IS the transform length, so the wave's DFT is one plain 2048-point transform -- no chirp,
+// no filter, no second pass, every bin used; 32 rows per wave instead of 16, G slots of 2048 entries, the window rows fetched with the samples
+// (no LDS left for them), W_N2^k0 as a per-lane times a per-row factor
+template <int W, bool EX = false> struct WideCfg {
     static constexpr int T = 4, R = 8 * T, M = 64 * R;                   // the sub-transform: L = 2048
     static constexpr int kWaves = 8, kGroups = kWaves / W;               // per workgroup
-    static constexpr int kRows = 16;                                     // rows of 64 points a wave fills: mp <= 1024
-    static constexpr int kRowsD = 17;                                    // rows of output bins per wave: (N2 + 1 <= W * 1024 + 1) / 64 / W, rounded up
-    static constexpr int kSlabW = 2 * 8 * kS1;                           // float2 per wave: the transform's exchange slab; then G_w[k0] (mp entries)
-    static constexpr int kRegion = W * kSlabW + 8;                       // per frame group; after the G exchange it holds Z[0..N2] (N2 + 1 <= W * 1024 + 1 entries)
-    // LDS tables, float2 units -- the device table has exactly this layout
-    static constexpr int kWin = 0;                                       // [W][1024] (w[2j], w[2j+1]), j = W a + w; zero for a >= mp
-    static constexpr int kChirp = kWin + W * 1024;                       // [1024] c[a] = exp(-i pi a^2 / mp)
-    static constexpr int kFilt = kChirp + 1024;                          // [16][64][2]: FFT_M(b) / M, rows 2i, 2i+1 of a lane side by side
-    static constexpr int kTw1 = kFilt + M;                               // [16][64][2] (31 rows, padded)
+    static constexpr int kRows = EX ? 32 : 16;                           // rows of 64 points a wave fills: mp <= 1024 (EX: mp = 2048)
+    static constexpr int kRowsD = EX ? 33 : 17;                          // rows of output bins per wave: (N2 + 1) / 64 / W, rounded up
+    static constexpr bool kPrefetch = !EX;                               // EX: no registers for the next frame's samples next to the transform
+    static constexpr int kSlabW = EX ? 2048 : 2 * 8 * kS1;               // float2 per wave: the transform's exchange slab (2 * 8 * kS1); then G_w[k0] (mp entries)
+    static constexpr int kRegion = W * kSlabW + 8;                       // per frame group; after the G exchange it holds Z[0..N2]
+    // LDS tables, float2 units -- the device table has exactly this layout (EX: then the window rows [W][2048])
+    static constexpr int kWin = 0;                                       // [W][1024] (w[2j], w[2j+1]), j = W a + w; zero for a >= mp           (EX: not in LDS)
+    static constexpr int kChirp = kWin + (EX ? 0 : W * 1024);            // [1024] c[a] = exp(-i pi a^2 / mp)                                     (EX: none)
+    static constexpr int kFilt = kChirp + (EX ? 0 : 1024);               // [16][64][2]: FFT_M(b) / M, rows 2i, 2i+1 of a lane side by side       (EX: none)
+    static constexpr int kTw1 = kFilt + (EX ? 0 : M);                    // [16][64][2] (31 rows, padded)
     static constexpr int kTw2 = kTw1 + R * 64;                           // [7][64]
-    static constexpr int kCtw = kTw2 + 7 * 64;                           // [1024] exp(-2 pi i k0 / N2)
-    static constexpr int kSrow = kCtw + 1024;                            // [64] exp(-2 pi i lane / n), then [.] exp(-2 pi i 64 rho / n), rho <= 67
+    static constexpr int kCtw = kTw2 + 7 * 64;                           // [1024] exp(-2 pi i k0 / N2)   (EX: [64] exp(-2 pi i lane / N2), then [32] exp(-2 pi i 64 c / N2), padded)
+    static constexpr int kSrow = kCtw + (EX ? 128 : 1024);               // [64] exp(-2 pi i lane / n), then [.] exp(-2 pi i 64 rho / n), rho <= 67
     static constexpr int kTabs = kSrow + 192;
+    static constexpr int kWinDev = kTabs;                                // EX, device table only: [W][2048] (w[2j], w[2j+1]), j = W a + w
     static constexpr int kMisc = 8;                                      // float2: partial sums [kGroups][W] and band partials [kGroups][W] (floats)
     static constexpr size_t kLdsBytes = (static_cast<size_t>(kTabs) + kGroups * kRegion + kMisc) * sizeof(float2);
 };
-static_assert(WideCfg<4>::kLdsBytes <= 160 * 1024 && WideCfg<2>::kLdsBytes <= 160 * 1024, "LDS of a CU");
+static_assert(WideCfg<4>::kLdsBytes <= 160 * 1024 && WideCfg<2>::kLdsBytes <= 160 * 1024 && WideCfg<2, true>::kLdsBytes <= 160 * 1024, "LDS of a CU");
 
 struct WideParams {
     const float* x;
@@ -58,17 +64,15 @@ struct WideParams {
     int64_t out_clip_stride;
     int n2, mp;                // nperseg / 2, n2 / W
     int aligned;               // every frame starts on an 8-byte boundary: one 8-byte load per point, else two 4-byte loads
-    const float2* tab;         // [kTabs]
+    const float2* tab;         // [kTabs] (EX: + [W][2048] window rows)
     float scale;
     int k_lo, k_hi;            // MODE 2: bins of the band
 };
 
 // MODE: 0 psd, 1 magnitude, 2 band power (A11)
-// DIRECT (nperseg 8192, W = 4: mp = 1024 = L / 2): the wave's DFT of mp points is every second bin of ONE zero-padded L-point transform --
-// no chirp, no filter, no second transform; half of that transform's bins are computed for nothing, which is still half the chirp-z work
-template <int W, bool DETREND, int MODE, bool DIRECT>
-__global__ __launch_bounds__((64 * WideCfg<W>::kWaves), 2) void stft_rbluew_kernel(const WideParams p) {
-    using C = WideCfg<W>;
+template <int W, bool DETREND, int MODE, bool EX>
+__global__ __launch_bounds__((64 * WideCfg<W, EX>::kWaves), 2) void stft_rbluew_kernel(const WideParams p) {
+    using C = WideCfg<W, EX>;
     constexpr int T = C::T, R = C::R, kWaves = C::kWaves;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int lane = threadIdx.x & 63;
@@ -80,14 +84,11 @@ __global__ __launch_bounds__((64 * WideCfg<W>::kWaves), 2) void stft_rbluew_kern
     float* const bpart = psum + kWaves;
 
     // ---- tables -> LDS (once per workgroup); sqrt of the PSD scale rides on the window ---------------------------------------------------
-    {
-        const float q_in = MODE != 1 ? p.scale * 0.5f : p.scale * 0.25f;       // bins 0 and N2 get 1/2 below
-        const float sq = sqrtf(q_in);
-        for (int i = threadIdx.x; i < C::kTabs; i += 64 * kWaves) {
-            float2 v = p.tab[i];
-            if (i < C::kChirp) { v.x *= sq; v.y *= sq; }
-            lds[i] = v;
-        }
+    const float sq = sqrtf(MODE != 1 ? p.scale * 0.5f : p.scale * 0.25f);      // bins 0 and N2 get 1/2 below
+    for (int i = threadIdx.x; i < C::kTabs; i += 64 * kWaves) {
+        float2 v = p.tab[i];
+        if (i < C::kChirp) { v.x *= sq; v.y *= sq; }
+        lds[i] = v;
     }
     __syncthreads();
 
@@ -137,10 +138,18 @@ __global__ __launch_bounds__((64 * WideCfg<W>::kWaves), 2) void stft_rbluew_kern
         return s / n_f;                                      // a true division: a constant clip must detrend to 0 exactly, as in scipy
     };
 
+    float2 winr[EX ? C::kRows : 1];                          // EX: this wave's window rows, fetched with every frame's samples (L2 hits)
+    auto load_window = [&]() {
+#pragma unroll
+        for (int a = 0; a < (EX ? C::kRows : 0); ++a) {
+            const float2 v = p.tab[C::kWinDev + w * 2048 + lane + 64 * a];
+            winr[a] = make_float2(v.x * sq, v.y * sq);
+        }
+    };
     float2 nxt[C::kRows];
-    load_frame(clip, f, nxt);                                // (a group without frames reads frame 0 of clip 0 and stores nothing)
+    if (C::kPrefetch) load_frame(clip, f, nxt);              // (a group without frames reads frame 0 of clip 0 and stores nothing)
     float mean = 0.f;
-    if (DETREND) {
+    if (DETREND && C::kPrefetch) {
         const float s = part_sum(nxt);
         if (lane == 0) psum[w] = s;
         __syncthreads();
@@ -153,14 +162,24 @@ __global__ __launch_bounds__((64 * WideCfg<W>::kWaves), 2) void stft_rbluew_kern
         float* const orow = p.out + static_cast<int64_t>(clip) * p.out_clip_stride + static_cast<int64_t>(f) * (MODE == 2 ? 1 : n2 + 1);
         const bool more = g + 1 < g_end;
         const int clip_n = !more ? clip : f + 1 == p.n_frames ? clip + 1 : clip, f_n = !more ? f : f + 1 == p.n_frames ? 0 : f + 1;
+        if (!C::kPrefetch) {                                 // samples and window rows fetched here; the mean costs a fifth barrier
+            load_window();
+            load_frame(clip, f, nxt);
+            if (DETREND) {
+                const float s = part_sum(nxt);
+                if (lane == 0) psum[w] = s;
+                __syncthreads();
+                mean = group_mean();
+            }
+        }
         float2 d[T][8], e[T][8];
         // ---- a[m] = (x[2j] w[2j] + i x[2j+1] w[2j+1]) * c[a], j = W a + w; rows beyond mp are zero (their window entries are) ----------------
 #pragma unroll
         for (int a = 0; a < R; ++a) {
             if (a < C::kRows) {
-                const float2 wn = lds_get(win + 64 * a);
+                const float2 wn = EX ? winr[EX ? a : 0] : lds_get(win + 64 * a);
                 const float x0 = (nxt[a].x - mean) * wn.x, x1 = (nxt[a].y - mean) * wn.y;
-                if (DIRECT) {
+                if (EX) {
                     d[a % T][a / T] = make_float2(x0, x1);
                 } else {
                     const float2 c = lds_get(chirp + 64 * a);
@@ -170,10 +189,10 @@ __global__ __launch_bounds__((64 * WideCfg<W>::kWaves), 2) void stft_rbluew_kern
                 d[a % T][a / T] = make_float2(0.f, 0.f);
             }
         }
-        load_frame(clip_n, f_n, nxt);                        // the group's last frame fetches itself again
+        if (C::kPrefetch) load_frame(clip_n, f_n, nxt);      // the group's last frame fetches itself again
         cfft_wave<T>(d, e, fl);
         // ---- Y = conj(A * B) -----------------------------------------------------------------------------------------------------------
-        if (!DIRECT) {
+        if (!EX) {
 #pragma unroll
         for (int c = 0; c < R; c += 2) {
             const v4f fb = lds_get2(lds + C::kFilt + (c >> 1) * 128 + 2 * lane);
@@ -185,19 +204,18 @@ __global__ __launch_bounds__((64 * WideCfg<W>::kWaves), 2) void stft_rbluew_kern
         cfft_wave<T>(d, e, fl);                              // e = V; the convolution is conj(V) (1 / L is in B)
         }
         // ---- G_w[k0] = W_N2^(w k0) * c[k0] * conj(V[k0]) -> this wave's slab ---------------------------------------------------------------
-        if (DIRECT) {                                        // F_w[k] = A[2k]: bin lane + 64 c of the transform is k = lane / 2 + 32 c for even lanes
+        if (EX) {                                            // F_w[k0] is the transform itself
 #pragma unroll
-            for (int c = 0; c < R; ++c) {
+            for (int c = 0; c < C::kRows; ++c) {
                 float2 z = e[c % T][c / T];
-                const int k = (lane >> 1) + 32 * c;
                 if (w != 0) {                                // wave-uniform
-                    const float2 t = lds_get(lds + C::kCtw + k);
+                    const float2 t = cmul(lds_get(lds + C::kCtw + lane), lds_get(lds + C::kCtw + 64 + c));
                     float2 pw = t;
                     if (w >= 2) pw = cmul(t, t);
                     if (w == 3) pw = cmul(pw, t);
                     z = cmul(z, pw);
                 }
-                if ((lane & 1) == 0) lds_put(slab + k, z);
+                lds_put(slab + lane + 64 * c, z);
             }
         } else {
 #pragma unroll
@@ -215,12 +233,12 @@ __global__ __launch_bounds__((64 * WideCfg<W>::kWaves), 2) void stft_rbluew_kern
             lds_put(slab + lane + 64 * c, z);
         }
         }
-        if (DETREND) {                                       // the next frame's samples have arrived by now
+        if (DETREND && C::kPrefetch) {                       // the next frame's samples have arrived by now
             const float s = part_sum(nxt);
             if (lane == 0) psum[w] = s;
         }
         __syncthreads();                                     // (1) every G_w and partial sum of the workgroup is in LDS
-        if (DETREND) mean = group_mean();
+        if (DETREND && C::kPrefetch) mean = group_mean();
         // ---- Z[k0 + w mp] = sum_v W_W^(v w) G_v[k0] ------------------------------------------------------------------------------------------
         float2 z[C::kRows];
 #pragma unroll
@@ -284,12 +302,12 @@ __global__ __launch_bounds__((64 * WideCfg<W>::kWaves), 2) void stft_rbluew_kern
     }
 }
 
-template <int W, bool DETREND, bool DIRECT>
+template <int W, bool DETREND, bool EX>
 int launch_wd(const WideParams& prm, hipStream_t s, int mode, bool band, int n_cu) {
-    using C = WideCfg<W>;
-    auto k0 = stft_rbluew_kernel<W, DETREND, 0, DIRECT>;
-    auto k1 = stft_rbluew_kernel<W, DETREND, 1, DIRECT>;
-    auto k2 = stft_rbluew_kernel<W, DETREND, 2, DIRECT>;
+    using C = WideCfg<W, EX>;
+    auto k0 = stft_rbluew_kernel<W, DETREND, 0, EX>;
+    auto k1 = stft_rbluew_kernel<W, DETREND, 1, EX>;
+    auto k2 = stft_rbluew_kernel<W, DETREND, 2, EX>;
     auto kern = band ? k2 : mode == SG_MODE_PSD ? k0 : k1;
     WideParams p = prm;
     int64_t n_groups = static_cast<int64_t>(n_cu) * C::kGroups;                 // one workgroup per CU (its tables fill the LDS)
@@ -303,7 +321,7 @@ int launch_wd(const WideParams& prm, hipStream_t s, int mode, bool band, int n_c
     return e == hipSuccess ? SG_OK : hip_fail(e, "stft_rbluew launch");
 }
 
-template <int W>
+template <int W, bool EX>
 int launch_w(const sg_plan& p, const StftArgs& a) {
     WideParams prm{};
     prm.x = static_cast<const float*>(a.x);
@@ -320,67 +338,59 @@ int launch_w(const sg_plan& p, const StftArgs& a) {
     prm.scale = static_cast<float>(p.scale);
     prm.k_lo = a.k_lo; prm.k_hi = a.k_hi;
     const bool band = a.band_mode != 0;                    // run_stft has checked: psd plan, 0 <= k_lo <= k_hi < n_bins
-    if (W == 4 && p.nfft == 8192)                          // mp = 1024 = L / 2: no chirp
-        return p.detrend == SG_DETREND_CONSTANT ? launch_wd<W, true, (W == 4)>(prm, a.stream, p.mode, band, p.n_cu)
-                                                : launch_wd<W, false, (W == 4)>(prm, a.stream, p.mode, band, p.n_cu);
-    return p.detrend == SG_DETREND_CONSTANT ? launch_wd<W, true, false>(prm, a.stream, p.mode, band, p.n_cu)
-                                            : launch_wd<W, false, false>(prm, a.stream, p.mode, band, p.n_cu);
+    return p.detrend == SG_DETREND_CONSTANT ? launch_wd<W, true, EX>(prm, a.stream, p.mode, band, p.n_cu)
+                                            : launch_wd<W, false, EX>(prm, a.stream, p.mode, band, p.n_cu);
 }
 
-template <int W>
+template <int W, bool EX>
 void fill_tables(std::vector<float2>& tab, const std::vector<double>& window, int n) {
-    using C = WideCfg<W>;
+    using C = WideCfg<W, EX>;
     constexpr int R = C::R, M = C::M;
     const int n2 = n / 2, mp = n2 / W;
     const long double pi = 3.14159265358979323846264338327950288L;
-    tab.assign(C::kTabs, make_float2(0.f, 0.f));
+    auto unit = [&](long double ang) { return make_float2(static_cast<float>(cosl(ang)), static_cast<float>(sinl(ang))); };
+    tab.assign(C::kTabs + (EX ? W * 2048 : 0), make_float2(0.f, 0.f));
     for (int w = 0; w < W; ++w)
         for (int a = 0; a < mp; ++a) {
             const int j = W * a + w;
-            tab[C::kWin + w * 1024 + a] = make_float2(static_cast<float>(window[2 * j]), static_cast<float>(window[2 * j + 1]));
+            tab[(EX ? C::kWinDev + w * 2048 : C::kWin + w * 1024) + a] = make_float2(static_cast<float>(window[2 * j]), static_cast<float>(window[2 * j + 1]));
         }
-    std::vector<double> br(mp), bi(mp);                      // b[j] = exp(+i pi j^2 / mp); j^2 mod 2 mp keeps the angle small
-    for (int j = 0; j < mp; ++j) {
-        const long long q = (static_cast<long long>(j) * j) % (2LL * mp);
-        const long double ang = pi * static_cast<long double>(q) / static_cast<long double>(mp);
-        br[j] = static_cast<double>(cosl(ang));
-        bi[j] = static_cast<double>(sinl(ang));
-        tab[C::kChirp + j] = make_float2(static_cast<float>(br[j]), static_cast<float>(-bi[j]));      // c[j] = conj b[j]
-    }
-    std::vector<double> hr(M, 0.0), hi(M, 0.0);
-    hr[0] = br[0]; hi[0] = bi[0];
-    for (int j = 1; j < mp; ++j) { hr[j] = hr[M - j] = br[j]; hi[j] = hi[M - j] = bi[j]; }
-    host_fft_pow2(hr, hi);
-    for (int k = 0; k < M; ++k) {
-        const int r = k >> 6, l = k & 63;
-        tab[C::kFilt + (r >> 1) * 128 + 2 * l + (r & 1)] = make_float2(static_cast<float>(hr[k] / M), static_cast<float>(hi[k] / M));
+    if (!EX) {
+        std::vector<double> br(mp), bi(mp);                  // b[j] = exp(+i pi j^2 / mp); j^2 mod 2 mp keeps the angle small
+        for (int j = 0; j < mp; ++j) {
+            const long long q = (static_cast<long long>(j) * j) % (2LL * mp);
+            const long double ang = pi * static_cast<long double>(q) / static_cast<long double>(mp);
+            br[j] = static_cast<double>(cosl(ang));
+            bi[j] = static_cast<double>(sinl(ang));
+            tab[C::kChirp + j] = make_float2(static_cast<float>(br[j]), static_cast<float>(-bi[j]));      // c[j] = conj b[j]
+        }
+        std::vector<double> hr(M, 0.0), hi(M, 0.0);
+        hr[0] = br[0]; hi[0] = bi[0];
+        for (int j = 1; j < mp; ++j) { hr[j] = hr[M - j] = br[j]; hi[j] = hi[M - j] = bi[j]; }
+        host_fft_pow2(hr, hi);
+        for (int k = 0; k < M; ++k) {
+            const int r = k >> 6, l = k & 63;
+            tab[C::kFilt + (r >> 1) * 128 + 2 * l + (r & 1)] = make_float2(static_cast<float>(hr[k] / M), static_cast<float>(hi[k] / M));
+        }
+        for (int k0 = 0; k0 < mp; ++k0) tab[C::kCtw + k0] = unit(-2.0L * pi * static_cast<long double>(k0) / static_cast<long double>(n2));
+    } else {                                                 // W_N2^k0, k0 = lane + 64 c, as a per-lane times a per-row factor
+        for (int l = 0; l < 64; ++l) tab[C::kCtw + l] = unit(-2.0L * pi * static_cast<long double>(l) / static_cast<long double>(n2));
+        for (int c = 0; c < C::kRows; ++c) tab[C::kCtw + 64 + c] = unit(-2.0L * pi * static_cast<long double>(64 * c) / static_cast<long double>(n2));
     }
     for (int l = 0; l < 64; ++l) {
-        for (int r = 1; r < R; ++r) {
-            const long double ang = -2.0L * pi * static_cast<long double>((static_cast<long long>(l) * r) % M) / M;
-            tab[C::kTw1 + ((r - 1) >> 1) * 128 + 2 * l + ((r - 1) & 1)] = make_float2(static_cast<float>(cosl(ang)), static_cast<float>(sinl(ang)));
-        }
-        for (int s = 1; s < 8; ++s) {
-            const long double ang = -2.0L * pi * static_cast<long double>(((l & 7) * s) % 64) / 64.0L;
-            tab[C::kTw2 + (s - 1) * 64 + l] = make_float2(static_cast<float>(cosl(ang)), static_cast<float>(sinl(ang)));
-        }
-        const long double ang = -2.0L * pi * static_cast<long double>(l) / static_cast<long double>(n);
-        tab[C::kSrow + l] = make_float2(static_cast<float>(cosl(ang)), static_cast<float>(sinl(ang)));
+        for (int r = 1; r < R; ++r)
+            tab[C::kTw1 + ((r - 1) >> 1) * 128 + 2 * l + ((r - 1) & 1)] = unit(-2.0L * pi * static_cast<long double>((static_cast<long long>(l) * r) % M) / M);
+        for (int s = 1; s < 8; ++s) tab[C::kTw2 + (s - 1) * 64 + l] = unit(-2.0L * pi * static_cast<long double>(((l & 7) * s) % 64) / 64.0L);
+        tab[C::kSrow + l] = unit(-2.0L * pi * static_cast<long double>(l) / static_cast<long double>(n));
     }
-    for (int k0 = 0; k0 < mp; ++k0) {
-        const long double ang = -2.0L * pi * static_cast<long double>(k0) / static_cast<long double>(n2);
-        tab[C::kCtw + k0] = make_float2(static_cast<float>(cosl(ang)), static_cast<float>(sinl(ang)));
-    }
-    for (int rho = 0; 64 * rho <= n2; ++rho) {
-        const long double ang = -2.0L * pi * static_cast<long double>(64 * rho) / static_cast<long double>(n);
-        tab[C::kSrow + 64 + rho] = make_float2(static_cast<float>(cosl(ang)), static_cast<float>(sinl(ang)));
-    }
+    for (int rho = 0; 64 * rho <= n2; ++rho) tab[C::kSrow + 64 + rho] = unit(-2.0L * pi * static_cast<long double>(64 * rho) / static_cast<long double>(n));
 }
 
 }  // namespace
 
 // wavefronts per frame of a plan rbluew_ok() accepts (spectro_api.hip)
-int rbluew_size(int nfft) { return nfft <= 4096 ? 2 : 4; }
+// (8192 itself: two waves, each ONE 2048-point transform, EX)
+int rbluew_size(int nfft) { return nfft <= 4096 || nfft == 8192 ? 2 : 4; }
 
 // (odd hops and clips at odd strides run here too, with 4-byte loads; int16 input is converted first, spectro_api.hip)
 bool rbluew_can_run(const sg_plan&, const StftArgs& a) {
@@ -389,14 +399,16 @@ bool rbluew_can_run(const sg_plan&, const StftArgs& a) {
 
 int launch_rbluew(const sg_plan& p, const StftArgs& a) {
     if (a.n_frames <= 0 || a.n_clips <= 0) return SG_OK;
-    return rbluew_size(p.nfft) == 2 ? launch_w<2>(p, a) : launch_w<4>(p, a);
+    if (p.nfft == 8192) return launch_w<2, true>(p, a);
+    return rbluew_size(p.nfft) == 2 ? launch_w<2, false>(p, a) : launch_w<4, false>(p, a);
 }
 
 // One device table in the kernel's LDS order (computed in double): window pairs per wave, chirp, filter spectrum, FFT twiddles,
 // W_N2^k0, split-twiddle factors.
 int build_rbluew_tables(sg_plan& p, const std::vector<double>& window) {
     std::vector<float2> tab;
-    if (rbluew_size(p.nfft) == 2) fill_tables<2>(tab, window, p.nfft); else fill_tables<4>(tab, window, p.nfft);
+    if (p.nfft == 8192) fill_tables<2, true>(tab, window, p.nfft);
+    else if (rbluew_size(p.nfft) == 2) fill_tables<2, false>(tab, window, p.nfft); else fill_tables<4, false>(tab, window, p.nfft);
     SG_HIP(hipMalloc(&p.rb_wc_dev, tab.size() * sizeof(float2)));
     SG_HIP(hipMemcpy(p.rb_wc_dev, tab.data(), tab.size() * sizeof(float2), hipMemcpyHostToDevice));
     return SG_OK;

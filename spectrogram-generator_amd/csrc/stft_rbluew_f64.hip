@@ -13,6 +13,7 @@
 // the frame mean riding on the prefetched samples of the next frame as there (prefetch issued after the second transform, its partial sums
 // exchanged with Z: the register file has no room for it during the transforms).  W = 8 has no room for either across the transforms (190-390
 // spilled dwords per lane when tried): its waves fetch samples and window rows at the top of the frame and the mean costs a fifth barrier.
+// nperseg 8192 itself runs here too, without the chirp: see WideDCfg<W, EX>.
 // Algorithmic HBM bytes per frame: hop*8 + (n/2+1)*8.
 #include "spectro_internal.h"
 #include "cfft_wave_f64.h"
@@ -25,26 +26,30 @@ namespace {
 
 using namespace wavefft64;
 
-template <int W> struct WideDCfg {
+// EX ("exact", nperseg 8192 on W = 4 waves): mp = 1024 IS the transform length, so the wave's DFT is one plain 1024-point transform -- no chirp,
+// no filter, no second pass, every bin used; 16 rows per wave instead of 8, G slots of 1024 entries, W_N2^k0 as a per-lane times a per-row factor
+template <int W, bool EX = false> struct WideDCfg {
     static constexpr int T = 2, R = 8 * T, M = 64 * R;                   // the sub-transform: L = 1024
     static constexpr int kWaves = 8, kGroups = kWaves / W;               // per workgroup
-    static constexpr int kRows = 8;                                      // rows of 64 points a wave fills: mp <= 512
-    static constexpr bool kPrefetch = W < 8;                             // W = 8: no room for the next frame's samples or resident window rows next to the transforms
-    static constexpr int kRowsD = 9;                                     // rows of output bins per wave: (N2 + 1 <= W * 512 + 1) / 64 / W, rounded up
-    static constexpr int kRegion = W * kSlab + 8;                        // elements per plane and frame group: the waves' exchange slabs; then G_w[k0]; then Z[0..N2]
+    static constexpr int kRows = EX ? 16 : 8;                            // rows of 64 points a wave fills: mp <= 512 (EX: mp = 1024)
+    static constexpr bool kPrefetch = !EX && W < 8;                      // W = 8, EX: no room for the next frame's samples or resident window rows next to the transforms
+    static constexpr int kRowsD = EX ? 17 : 9;                           // rows of output bins per wave: (N2 + 1) / 64 / W, rounded up
+    static constexpr int kSlot = EX ? 1024 : kSlab;                      // elements per plane and wave: its exchange slab (kSlab), then G_w[k0]
+    static constexpr int kRegion = W * kSlot + 8;                        // per plane and frame group; after the G exchange it holds Z[0..N2]
     // complex table entries (each a real and an imaginary plane element) -- the device table has this order, then the window rows
-    static constexpr int kChirp = 0;                                     // [512] c[a] = exp(-i pi a^2 / mp)
-    static constexpr int kFilt = kChirp + 512;                           // [R][64]: FFT_M(b) / M
-    static constexpr int kTw1 = kFilt + M;                               // [R - 1][64]
+    static constexpr int kChirp = 0;                                     // [512] c[a] = exp(-i pi a^2 / mp)                      (EX: none)
+    static constexpr int kFilt = kChirp + (EX ? 0 : 512);                // [R][64]: FFT_M(b) / M                                 (EX: none)
+    static constexpr int kTw1 = kFilt + (EX ? 0 : M);                    // [R - 1][64]
     static constexpr int kTw2 = kTw1 + (R - 1) * 64;                     // [7][64]
-    static constexpr int kCtw = kTw2 + 7 * 64;                           // [512] exp(-2 pi i k0 / N2)
-    static constexpr int kSrow = kCtw + 512;                             // [64] exp(-2 pi i lane / n), then [.] exp(-2 pi i 64 rho / n), rho <= 71
+    static constexpr int kCtw = kTw2 + 7 * 64;                           // [512] exp(-2 pi i k0 / N2)   (EX: [64] exp(-2 pi i lane / N2), then [16] exp(-2 pi i 64 c / N2), padded)
+    static constexpr int kSrow = kCtw + (EX ? 128 : 512);                // [64] exp(-2 pi i lane / n), then [.] exp(-2 pi i 64 rho / n), rho <= 71
     static constexpr int kTabs = kSrow + 192;
-    static constexpr int kWinDev = kTabs;                                // device table only: [W][512] (w[2j], w[2j+1]), j = W a + w, zero for a >= mp
+    static constexpr int kWinStride = EX ? 1024 : 512;
+    static constexpr int kWinDev = kTabs;                                // device table only: [W][kWinStride] (w[2j], w[2j+1]), j = W a + w, zero for a >= mp
     static constexpr int kMisc = 16;                                     // doubles: partial sums [kGroups][W], band partials [kGroups][W]
     static constexpr size_t kLdsBytes = (2 * static_cast<size_t>(kTabs) + 2 * static_cast<size_t>(kGroups) * kRegion + kMisc) * sizeof(double);
 };
-static_assert(WideDCfg<2>::kLdsBytes <= 160 * 1024 && WideDCfg<8>::kLdsBytes <= 160 * 1024, "LDS of a CU");
+static_assert(WideDCfg<2>::kLdsBytes <= 160 * 1024 && WideDCfg<8>::kLdsBytes <= 160 * 1024 && WideDCfg<4, true>::kLdsBytes <= 160 * 1024, "LDS of a CU");
 
 struct WideDParams {
     const double* x;
@@ -56,16 +61,15 @@ struct WideDParams {
     int64_t out_clip_stride;
     int n2, mp;                // nperseg / 2, n2 / W
     int aligned;               // every frame starts on a 16-byte boundary: one 16-byte load per point, else two 8-byte loads
-    const double2* tabs;       // [kTabs + W * 512]
+    const double2* tabs;       // [kTabs + W * kWinStride]
     double scale;
     int k_lo, k_hi;            // MODE 2: bins of the band
 };
 
 // MODE: 0 psd, 1 magnitude, 2 band power (A11)
-// DIRECT (nperseg 8192, W = 8: mp = 512 = L / 2): the wave's DFT of mp points is every second bin of ONE zero-padded L-point transform (stft_rbluew.hip)
-template <int W, bool DETREND, int MODE, bool DIRECT>
-__global__ __launch_bounds__((64 * WideDCfg<W>::kWaves), 2) void stft_rbluew_f64_kernel(const WideDParams p) {
-    using C = WideDCfg<W>;
+template <int W, bool DETREND, int MODE, bool EX>
+__global__ __launch_bounds__((64 * WideDCfg<W, EX>::kWaves), 2) void stft_rbluew_f64_kernel(const WideDParams p) {
+    using C = WideDCfg<W, EX>;
     constexpr int T = C::T, R = C::R, kWaves = C::kWaves;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x & 63;
@@ -74,7 +78,7 @@ __global__ __launch_bounds__((64 * WideDCfg<W>::kWaves), 2) void stft_rbluew_f64
     const Planes tab{lds, lds + C::kTabs};
     double* const rg = lds + 2 * C::kTabs + grp * 2 * C::kRegion;
     const Planes region{rg, rg + C::kRegion};
-    const Planes sl{rg + w * kSlab, rg + C::kRegion + w * kSlab};             // this wave's slab inside the group's region
+    const Planes sl{rg + w * C::kSlot, rg + C::kRegion + w * C::kSlot};       // this wave's slot inside the group's region: exchange slab, then G_w
     double* const psum = lds + 2 * C::kTabs + 2 * C::kGroups * C::kRegion + grp * W;
     double* const bpart = psum + kWaves;
 
@@ -98,7 +102,7 @@ __global__ __launch_bounds__((64 * WideDCfg<W>::kWaves), 2) void stft_rbluew_f64
     auto load_window = [&]() {
 #pragma unroll
         for (int a = 0; a < C::kRows; ++a) {
-            const double2 v = p.tabs[C::kWinDev + w * 512 + lane + 64 * a];
+            const double2 v = p.tabs[C::kWinDev + w * C::kWinStride + lane + 64 * a];
             win[a] = {v.x * sq, v.y * sq};
         }
     };
@@ -168,13 +172,13 @@ __global__ __launch_bounds__((64 * WideDCfg<W>::kWaves), 2) void stft_rbluew_f64
         for (int a = 0; a < R; ++a) {
             if (a < C::kRows) {
                 const cd xw = {(nxt[a].x - mean) * win[a].x, (nxt[a].y - mean) * win[a].y};
-                d[a % T][a / T] = DIRECT ? xw : cmul(xw, tab_l.get(C::kChirp + 64 * a));
+                d[a % T][a / T] = EX ? xw : cmul(xw, tab_l.get(C::kChirp + 64 * a));
             } else {
                 d[a % T][a / T] = cd{0.0, 0.0};
             }
         }
         cfft_wave_f64<T>(d, e, tab, C::kTw1, C::kTw2, sl, lane);
-        if (!DIRECT) {
+        if (!EX) {
 #pragma unroll
             for (int c = 0; c < R; ++c) {                    // Y = conj(A * B)
                 const cd y = cmul(e[c % T][c / T], tab_l.get(C::kFilt + 64 * c));
@@ -183,23 +187,20 @@ __global__ __launch_bounds__((64 * WideDCfg<W>::kWaves), 2) void stft_rbluew_f64
             cfft_wave_f64<T>(d, e, tab, C::kTw1, C::kTw2, sl, lane);         // e = V; the convolution is conj(V) (1 / L is in B)
         }
         if (C::kPrefetch) load_frame(clip_n, f_n, nxt);      // prefetch, issued where the register file has room for it (the group's last frame fetches itself again)
-        // ---- G_w[k0] = W_N2^(w k0) * c[k0] * conj(V[k0]) -> this wave's slab ----
+        // ---- G_w[k0] = W_N2^(w k0) * c[k0] * conj(V[k0]) -> this wave's slot (EX: F_w[k0] is the transform itself) ----
 #pragma unroll
-        for (int c = 0; c < (DIRECT ? R : C::kRows); ++c) {
-            // DIRECT: F_w[k] = A[2k]: bin lane + 64 c of the transform is k = lane / 2 + 32 c for even lanes
-            const int k = DIRECT ? (lane >> 1) + 32 * c : lane + 64 * c;
+        for (int c = 0; c < C::kRows; ++c) {
             const cd v = e[c % T][c / T];
-            cd z = DIRECT ? v : cmul(cd{v.x, -v.y}, tab_l.get(C::kChirp + 64 * c));
+            cd z = EX ? v : cmul(cd{v.x, -v.y}, tab_l.get(C::kChirp + 64 * c));
             if (w != 0) {                                    // wave-uniform: t^w by squaring
-                const cd t = DIRECT ? tab.get(C::kCtw + k) : tab_l.get(C::kCtw + 64 * c);
+                const cd t = EX ? cmul(tab_l.get(C::kCtw), tab.get(C::kCtw + 64 + c)) : tab_l.get(C::kCtw + 64 * c);
                 const cd t2 = cmul(t, t);
                 cd pw = (w & 1) ? t : cd{1.0, 0.0};
                 if (w & 2) pw = (w & 1) ? cmul(pw, t2) : t2;
                 if (W > 4 && (w & 4)) { const cd t4 = cmul(t2, t2); pw = (w & 3) ? cmul(pw, t4) : t4; }
                 z = cmul(z, pw);
             }
-            if (!DIRECT) sl_l.put(64 * c, z);
-            else if ((lane & 1) == 0) sl.put(k, z);
+            sl_l.put(64 * c, z);
         }
         __syncthreads();                                     // (1) every G_w of the workgroup is in LDS
         // ---- Z[k0 + w mp] = sum_v W_W^(v w) G_v[k0] ----
@@ -223,7 +224,7 @@ __global__ __launch_bounds__((64 * WideDCfg<W>::kWaves), 2) void stft_rbluew_f64
             cd acc = region_l.get(64 * c);              // v = 0: coefficient 1
 #pragma unroll
             for (int v = 1; v < W; ++v) {
-                const cd gv = region_l.get(v * kSlab + 64 * c);
+                const cd gv = region_l.get(v * C::kSlot + 64 * c);
                 acc.x += gv.x * bw_re[v] - gv.y * bw_im[v];
                 acc.y += gv.x * bw_im[v] + gv.y * bw_re[v];
             }
@@ -285,12 +286,12 @@ __global__ __launch_bounds__((64 * WideDCfg<W>::kWaves), 2) void stft_rbluew_f64
     }
 }
 
-template <int W, bool DETREND, bool DIRECT>
+template <int W, bool DETREND, bool EX>
 int launch_wd(const WideDParams& prm, hipStream_t s, int mode, bool band, int n_cu) {
-    using C = WideDCfg<W>;
-    auto k0 = stft_rbluew_f64_kernel<W, DETREND, 0, DIRECT>;
-    auto k1 = stft_rbluew_f64_kernel<W, DETREND, 1, DIRECT>;
-    auto k2 = stft_rbluew_f64_kernel<W, DETREND, 2, DIRECT>;
+    using C = WideDCfg<W, EX>;
+    auto k0 = stft_rbluew_f64_kernel<W, DETREND, 0, EX>;
+    auto k1 = stft_rbluew_f64_kernel<W, DETREND, 1, EX>;
+    auto k2 = stft_rbluew_f64_kernel<W, DETREND, 2, EX>;
     auto kern = band ? k2 : mode == SG_MODE_PSD ? k0 : k1;
     WideDParams p = prm;
     int64_t n_groups = static_cast<int64_t>(n_cu) * C::kGroups;                 // one workgroup per CU
@@ -304,7 +305,7 @@ int launch_wd(const WideDParams& prm, hipStream_t s, int mode, bool band, int n_
     return e == hipSuccess ? SG_OK : hip_fail(e, "stft_rbluew_f64 launch");
 }
 
-template <int W>
+template <int W, bool EX>
 int launch_w(const sg_plan& p, const StftArgs& a) {
     WideDParams prm{};
     prm.x = static_cast<const double*>(a.x);
@@ -321,11 +322,8 @@ int launch_w(const sg_plan& p, const StftArgs& a) {
     prm.scale = p.scale;
     prm.k_lo = a.k_lo; prm.k_hi = a.k_hi;
     const bool band = a.band_mode != 0;                    // run_stft has checked: psd plan, 0 <= k_lo <= k_hi < n_bins
-    if (W == 8 && p.nfft == 8192)                          // mp = 512 = L / 2: no chirp
-        return p.detrend == SG_DETREND_CONSTANT ? launch_wd<W, true, (W == 8)>(prm, a.stream, p.mode, band, p.n_cu)
-                                                : launch_wd<W, false, (W == 8)>(prm, a.stream, p.mode, band, p.n_cu);
-    return p.detrend == SG_DETREND_CONSTANT ? launch_wd<W, true, false>(prm, a.stream, p.mode, band, p.n_cu)
-                                            : launch_wd<W, false, false>(prm, a.stream, p.mode, band, p.n_cu);
+    return p.detrend == SG_DETREND_CONSTANT ? launch_wd<W, true, EX>(prm, a.stream, p.mode, band, p.n_cu)
+                                            : launch_wd<W, false, EX>(prm, a.stream, p.mode, band, p.n_cu);
 }
 
 void host_fft_ld(std::vector<long double>& re, std::vector<long double>& im) {      // radix-2, once per plan, for the filter spectrum
@@ -351,28 +349,43 @@ void host_fft_ld(std::vector<long double>& re, std::vector<long double>& im) {  
     }
 }
 
-template <int W>
+template <int W, bool EX>
 void fill_tables(std::vector<double>& t, const std::vector<double>& window, int n) {
-    using C = WideDCfg<W>;
+    using C = WideDCfg<W, EX>;
     constexpr int R = C::R, M = C::M;
     const int n2 = n / 2, mp = n2 / W;
     const long double pi = 3.14159265358979323846264338327950288L;
-    t.assign(2 * (static_cast<size_t>(C::kTabs) + W * 512), 0.0);
+    t.assign(2 * (static_cast<size_t>(C::kTabs) + W * C::kWinStride), 0.0);
     auto put = [&](int i, long double re, long double im) { t[2 * static_cast<size_t>(i)] = static_cast<double>(re); t[2 * static_cast<size_t>(i) + 1] = static_cast<double>(im); };
     for (int w = 0; w < W; ++w)
-        for (int a = 0; a < mp; ++a) put(C::kWinDev + w * 512 + a, window[2 * (W * a + w)], window[2 * (W * a + w) + 1]);
-    std::vector<long double> br(mp), bi(mp);                 // b[j] = exp(+i pi j^2 / mp); j^2 mod 2 mp keeps the angle small
-    for (int j = 0; j < mp; ++j) {
-        const long long q = (static_cast<long long>(j) * j) % (2LL * mp);
-        const long double ang = pi * static_cast<long double>(q) / static_cast<long double>(mp);
-        br[j] = cosl(ang); bi[j] = sinl(ang);
-        put(C::kChirp + j, br[j], -bi[j]);                   // c[j] = conj b[j]
+        for (int a = 0; a < mp; ++a) put(C::kWinDev + w * C::kWinStride + a, window[2 * (W * a + w)], window[2 * (W * a + w) + 1]);
+    if (!EX) {
+        std::vector<long double> br(mp), bi(mp);             // b[j] = exp(+i pi j^2 / mp); j^2 mod 2 mp keeps the angle small
+        for (int j = 0; j < mp; ++j) {
+            const long long q = (static_cast<long long>(j) * j) % (2LL * mp);
+            const long double ang = pi * static_cast<long double>(q) / static_cast<long double>(mp);
+            br[j] = cosl(ang); bi[j] = sinl(ang);
+            put(C::kChirp + j, br[j], -bi[j]);               // c[j] = conj b[j]
+        }
+        std::vector<long double> hr(M, 0.0L), hi(M, 0.0L);
+        hr[0] = br[0]; hi[0] = bi[0];
+        for (int j = 1; j < mp; ++j) { hr[j] = hr[M - j] = br[j]; hi[j] = hi[M - j] = bi[j]; }
+        host_fft_ld(hr, hi);
+        for (int k = 0; k < M; ++k) put(C::kFilt + k, hr[k] / M, hi[k] / M);
+        for (int k0 = 0; k0 < mp; ++k0) {
+            const long double ang = -2.0L * pi * static_cast<long double>(k0) / static_cast<long double>(n2);
+            put(C::kCtw + k0, cosl(ang), sinl(ang));
+        }
+    } else {                                                 // W_N2^k0, k0 = lane + 64 c, as a per-lane times a per-row factor
+        for (int l = 0; l < 64; ++l) {
+            const long double ang = -2.0L * pi * static_cast<long double>(l) / static_cast<long double>(n2);
+            put(C::kCtw + l, cosl(ang), sinl(ang));
+        }
+        for (int c = 0; c < C::kRows; ++c) {
+            const long double ang = -2.0L * pi * static_cast<long double>(64 * c) / static_cast<long double>(n2);
+            put(C::kCtw + 64 + c, cosl(ang), sinl(ang));
+        }
     }
-    std::vector<long double> hr(M, 0.0L), hi(M, 0.0L);
-    hr[0] = br[0]; hi[0] = bi[0];
-    for (int j = 1; j < mp; ++j) { hr[j] = hr[M - j] = br[j]; hi[j] = hi[M - j] = bi[j]; }
-    host_fft_ld(hr, hi);
-    for (int k = 0; k < M; ++k) put(C::kFilt + k, hr[k] / M, hi[k] / M);
     for (int l = 0; l < 64; ++l) {
         for (int r = 1; r < R; ++r) {
             const long double ang = -2.0L * pi * static_cast<long double>((static_cast<long long>(l) * r) % M) / M;
@@ -385,10 +398,6 @@ void fill_tables(std::vector<double>& t, const std::vector<double>& window, int 
         const long double ang = -2.0L * pi * static_cast<long double>(l) / static_cast<long double>(n);
         put(C::kSrow + l, cosl(ang), sinl(ang));
     }
-    for (int k0 = 0; k0 < mp; ++k0) {
-        const long double ang = -2.0L * pi * static_cast<long double>(k0) / static_cast<long double>(n2);
-        put(C::kCtw + k0, cosl(ang), sinl(ang));
-    }
     for (int rho = 0; 64 * rho <= n2; ++rho) {
         const long double ang = -2.0L * pi * static_cast<long double>(64 * rho) / static_cast<long double>(n);
         put(C::kSrow + 64 + rho, cosl(ang), sinl(ang));
@@ -397,8 +406,8 @@ void fill_tables(std::vector<double>& t, const std::vector<double>& window, int 
 
 }  // namespace
 
-// wavefronts per frame of a plan rbluewd_ok() accepts (spectro_api.hip)
-int rbluew_f64_size(int nfft) { return nfft <= 2048 ? 2 : nfft <= 4096 ? 4 : 8; }
+// wavefronts per frame of a plan rbluewd_ok() accepts (spectro_api.hip); 8192 itself: four waves, each ONE 1024-point transform (EX)
+int rbluew_f64_size(int nfft) { return nfft <= 2048 ? 2 : nfft <= 4096 || nfft == 8192 ? 4 : 8; }
 
 bool rbluew_f64_can_run(const sg_plan& p, const StftArgs& a) {
     return p.dtype == SG_F64 && !a.in_i16 && !a.db_mode && a.mel_ipl == 0 && (reinterpret_cast<uintptr_t>(a.x) % 8 == 0) && a.n_frames <= INT32_MAX;
@@ -406,15 +415,17 @@ bool rbluew_f64_can_run(const sg_plan& p, const StftArgs& a) {
 
 int launch_rbluew_f64(const sg_plan& p, const StftArgs& a) {
     if (a.n_frames <= 0 || a.n_clips <= 0) return SG_OK;
+    if (p.nfft == 8192) return launch_w<4, true>(p, a);
     const int W = rbluew_f64_size(p.nfft);
-    return W == 2 ? launch_w<2>(p, a) : W == 4 ? launch_w<4>(p, a) : launch_w<8>(p, a);
+    return W == 2 ? launch_w<2, false>(p, a) : W == 4 ? launch_w<4, false>(p, a) : launch_w<8, false>(p, a);
 }
 
 // one table of (re, im) pairs in the order of WideDCfg (LDS part, then the window rows per wave), computed in long double
 int build_rbluew_f64_tables(sg_plan& p, const std::vector<double>& window) {
     std::vector<double> t;
     const int W = rbluew_f64_size(p.nfft);
-    if (W == 2) fill_tables<2>(t, window, p.nfft); else if (W == 4) fill_tables<4>(t, window, p.nfft); else fill_tables<8>(t, window, p.nfft);
+    if (p.nfft == 8192) fill_tables<4, true>(t, window, p.nfft);
+    else if (W == 2) fill_tables<2, false>(t, window, p.nfft); else if (W == 4) fill_tables<4, false>(t, window, p.nfft); else fill_tables<8, false>(t, window, p.nfft);
     SG_HIP(hipMalloc(&p.rb_wc_dev, t.size() * sizeof(double)));
     SG_HIP(hipMemcpy(p.rb_wc_dev, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
     return SG_OK;
