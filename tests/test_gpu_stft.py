@@ -1122,7 +1122,7 @@ def test_rbluew_kernel(sp, n, hop, detrend, mode, window):
     assert_spec_close(s[keep], s_lds[keep], time_axis=-1, bin_floor=floor)
 
 
-@pytest.mark.parametrize("n,hop,clips,frames", [(2080, 64, 3, 701), (4128, 96, 2, 1031), (2400, 32, 1, 1025), (8000, 4000, 1, 1)])
+@pytest.mark.parametrize("n,hop,clips,frames", [(2080, 64, 3, 701), (4128, 96, 2, 1031), (2400, 32, 1, 1025), (8000, 4000, 1, 1), (8192, 64, 2, 641)])
 def test_rbluew_many_frames_band_power_and_int16(sp, n, hop, clips, frames):
     """More frames than the launch has frame groups (1 024 / 512: every group loops, the last pass is ragged) and a single frame; the fused
     band power (A11) == the sum over the written bins; int16 batches (converted once on the device) == the float call; clips at an
@@ -1141,7 +1141,9 @@ def test_rbluew_many_frames_band_power_and_int16(sp, n, hop, clips, frames):
     assert s.shape == so.shape == (clips, n // 2 + 1, frames)
     # (per-bin bound 3e-4 over these 1-2 M bins: the tail of float32 rounding at bins 1e-3 of the frame maximum -- scipy's own float32
     # path shows 1.8e-4 / 2.0e-4 on the same inputs, this kernel 1.3e-4 / 1.7e-4, tools/acc_np2.py; frame and norm bounds as everywhere)
-    assert_spec_close(s, so, time_axis=-1, bin_rtol=3e-4)
+    # (nperseg 8192, 5.2 M bins: 6e-4 -- the oracle computes in the input's precision as scipy does, so BOTH sides carry float32 rounding: against
+    # float64 truth this kernel shows 2.0e-4, scipy's float32 path 2.7e-4, tools/acc_np2.py)
+    assert_spec_close(s, so, time_axis=-1, bin_rtol=3e-4 if n < 8192 else 6e-4)
     nfr, nb = plan.n_frames(ns), n // 2 + 1
     d_in, d_bp = _capi.DeviceBuffer(x.nbytes), _capi.DeviceBuffer(clips * nfr * 4)
     d_in.upload(x)
@@ -1164,7 +1166,7 @@ def test_rbluew_many_frames_band_power_and_int16(sp, n, hop, clips, frames):
         xs = x[:, :ns - 1] if (ns - 1) % 2 else x[:, :ns - 2]
         _, _, s1 = sp.spectrogram(xs, **kw)
         _, _, so1 = orc.spectrogram(xs, **kw)
-        assert_spec_close(s1, so1, time_axis=-1, bin_rtol=3e-4)
+        assert_spec_close(s1, so1, time_axis=-1, bin_rtol=3e-4 if n < 8192 else 6e-4)
 
 
 @pytest.mark.parametrize("n,hop,detrend,mode,window", [
@@ -1223,7 +1225,7 @@ def test_rbluew_f64_kernel(sp, n, hop, detrend, mode, window):
         d_in.free(); d_bp.free()
 
 
-@pytest.mark.parametrize("n,hop,clips,frames", [(1056, 32, 3, 701), (2080, 48, 2, 531), (4112, 16, 1, 259), (4112, 2000, 1, 1)])
+@pytest.mark.parametrize("n,hop,clips,frames", [(1056, 32, 3, 701), (2080, 48, 2, 531), (4112, 16, 1, 259), (4112, 2000, 1, 1), (8192, 32, 3, 301)])
 def test_rbluew_f64_many_frames(sp, n, hop, clips, frames):
     """More frames than the launch has frame groups (1 024 / 512 / 256: every group loops, the last pass is ragged) and a single frame."""
     rng = np.random.default_rng(n * 5 + hop)

@@ -7,7 +7,7 @@ from spectro import _capi
 from spectro.signal import plan_for
 from spectro.windows import get_window
 from oracle import stft_oracle as orc
-for n, hop, clips, frames in [(2080, 64, 3, 701), (4128, 96, 2, 1031), (2016, 64, 3, 701), (2048, 64, 3, 701)]:
+for n, hop, clips, frames in [(2080, 64, 3, 701), (4128, 96, 2, 1031), (2016, 64, 3, 701), (2048, 64, 3, 701), (8192, 64, 2, 641), (4096, 64, 2, 641)]:
     rng = np.random.default_rng(n * 7 + hop)
     ns = n + hop * (frames - 1) + 3
     x = (rng.standard_normal((clips, ns)) * 0.3 + 0.5).astype(np.float32)
