@@ -628,3 +628,18 @@ def test_hip_runtime_preload_checks_the_soname(tmp_path):
     assert r.returncode == 0 and "choice=torch path=" in r.stdout and "torch/lib/libamdhip64.so" in r.stdout, r.stdout + r.stderr[-400:]
     r = subprocess.run([sys.executable, "-c", real, PKG], capture_output=True, text=True, env=dict(env, SPECTRO_HIP_RUNTIME="system"), timeout=120)
     assert r.returncode == 0 and "choice=system path=None" in r.stdout, r.stdout + r.stderr[-400:]
+
+
+@pytest.mark.parametrize("tool", ["sim_rtiny.py", "sim_rbluew.py", "sim_rsmall.py"])
+def test_lane_models_of_the_register_kernels(tool):
+    """The numpy models the register kernels' index maps were written against (tools/sim_*.py: radix-8 + quad-DPP transform of stft_rtiny.hip,
+    the decimation-in-time / chirp-z / split algebra of stft_rbluew*.hip, rsmall's maps incl. R = 1) still reproduce numpy's rfft: the CPU-side
+    check of what the GPU tests check against the oracle."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", tool)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    errs = [float(m) for m in re.findall(r"max rel err ([0-9.eE+-]+)", out.stdout)]
+    assert len(errs) >= 2 and max(errs) < 1e-12, out.stdout
+
