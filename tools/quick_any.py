@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Sustained timing of whatever kernel a plan picks: python tools/quick_any.py 8192:2048:f32 64:16:f64 ... (nperseg:hop:dtype[:clips])"""
+"""Sustained timing of whatever kernel a plan picks: python tools/quick_any.py 8192:2048:f32 64:16:f64 ... (nperseg:hop:dtype[:clips]; QA_SECS = seconds per leg, default 0.5)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "spectrogram-generator_amd"))
@@ -24,7 +24,7 @@ for spec in sys.argv[1:]:
     fn = lambda: plan.stft(d_in.ptr, N, N, n_clips, out.ptr, nf * (n // 2 + 1))
     fn(); _capi.stream_sync()
     k, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < 0.5:
+    while time.perf_counter() - t0 < float(os.environ.get("QA_SECS", "0.5")):
         fn(); k += 1
         if k % 8 == 0: _capi.stream_sync()
     _capi.stream_sync()
