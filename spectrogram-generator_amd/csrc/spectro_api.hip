@@ -38,7 +38,8 @@ static bool rsmall_ok(const sg_plan& p) {
 
 // nperseg 32 / 64, f32 and f64: the quad-DPP register kernel (stft_rtiny.hip)
 static bool rtiny_ok(const sg_plan& p) {
-    return (p.dtype == SG_F32 || p.dtype == SG_F64) && p.nperseg == p.nfft && (p.nfft == 32 || p.nfft == 64) &&
+    const bool small_np2 = p.dtype == SG_F32 && (p.nfft == 96 || p.nfft == 160 || p.nfft == 192 || p.nfft == 224);     // Q = 6 / 10 / 12 / 14 lanes per frame
+    return (p.dtype == SG_F32 || p.dtype == SG_F64) && p.nperseg == p.nfft && (p.nfft == 32 || p.nfft == 64 || small_np2) &&
            (p.detrend == SG_DETREND_NONE || p.detrend == SG_DETREND_CONSTANT) &&
            (p.mode == SG_MODE_PSD || p.mode == SG_MODE_MAGNITUDE);
 }
@@ -236,14 +237,18 @@ static int run_stft(const sg_plan* plan, StftArgs& a) {
     if (a.in_i16 && (plan->kernel == Kernel::RSMALL || plan->kernel == Kernel::RBIG || (plan->kernel == Kernel::RTINY && plan->dtype == SG_F32)) && plan->hop % 2 == 0 &&
         (a.clip_stride % 2 == 0 || a.n_clips == 1) && static_cast<int64_t>(a.n_clips) * a.n_samples >= (1 << 18))
         return run_converted(plan, a);
-    if ((plan->kernel == Kernel::RBLUE || plan->kernel == Kernel::RBLUEW) && a.in_i16) return run_converted(plan, a);     // no chirp-z kernel loads int16
+    if ((plan->kernel == Kernel::RBLUE || plan->kernel == Kernel::RBLUEW || (plan->kernel == Kernel::RTINY && !is_pow2(plan->nfft))) && a.in_i16)
+        return run_converted(plan, a);                       // no chirp-z kernel loads int16 (nor does rtiny, whose fallback at these sizes is one)
     switch (plan->kernel) {
         case Kernel::R8X3: return launch_r8x3(*plan, a);
         case Kernel::R8X3D: return r8x3_f64_can_run(*plan, a) ? launch_r8x3_f64(*plan, a) : launch_stockham(*plan, a);
         case Kernel::RSMALL: return rsmall_can_run(*plan, a) ? launch_rsmall(*plan, a) : launch_stockham(*plan, a);
         case Kernel::RBIG: return rbig_can_run(*plan, a) ? launch_rbig(*plan, a) : launch_stockham(*plan, a);
         case Kernel::RBIGD: return rbig_f64_can_run(*plan, a) ? launch_rbig_f64(*plan, a) : launch_stockham(*plan, a);
-        case Kernel::RTINY: return rtiny_can_run(*plan, a) ? launch_rtiny(*plan, a) : launch_stockham(*plan, a);
+        case Kernel::RTINY:
+            if (rtiny_can_run(*plan, a)) return launch_rtiny(*plan, a);
+            if (is_pow2(plan->nfft)) return launch_stockham(*plan, a);
+            return a.band_mode ? band_via_spectrum(plan, a) : launch_bluestein_lazy(plan, a);      // nperseg 96 / 160 / 192 / 224: odd hops, GUI-sized int16 calls
         case Kernel::STOCKHAM: return launch_stockham(*plan, a);
         case Kernel::BLUESTEIN: return launch_bluestein(*plan, a);
         // odd hops / unaligned clips, GUI-sized int16 calls: the LDS chirp-z kernel (its tables are built with the plan); it writes full spectra only

@@ -10,6 +10,11 @@
 // (8 - k1) + 8 (Q - 1 - k2): the mirror lane of the same quad -- DPP again.  So the transform itself touches no LDS and has no barrier; LDS
 // only stages the G finished rows (G * (N2 + 1) consecutive values in HBM) so that they leave as contiguous 16-byte stores, as in
 // stft_rsmall.hip.  Lane-level model of the index maps: tools/sim_rtiny.py.
+//
+// f32 only, nperseg 96 / 160 / 192 / 224 (Q = 6 / 10 / 12 / 14: the spin box's sizes below 256 that are no power of two; the chirp-z kernel ran
+// them on 512-point transforms): the same frame layout on Q lanes (floor(64 / Q) frames per wave step, the last 4 or 8 lanes idle), the Q-point
+// DFT across the frame's lanes as a direct sum through LDS (Q complex multiply-adds per bin, the Q coefficients W_Q^(j k2) in registers), the
+// split's mirror lane by ds_bpermute.
 // Algorithmic HBM bytes per frame: hop * s + (n/2 + 1) * s, s = 4 / 8.
 #include "spectro_internal.h"
 
@@ -83,18 +88,19 @@ template <typename R> struct TinyParams {
     R* out;
     int64_t out_clip_stride;
     const R* win;             // [n]
-    const R* tw;              // [16][64][2]: rows 0..7 W_N2^(j k1) (row 0 = 1), rows 8..15 exp(-2 pi i (k1 + 8 k2) / n), per lane
+    const R* tw;              // [16 (+ Q)][64][2]: rows 0..7 W_N2^(j k1) (row 0 = 1), rows 8..15 exp(-2 pi i (k1 + 8 k2) / n), rows 16.. W_Q^(jj k2), per lane
     R scale;
     int k_lo, k_hi;           // MODE 2: bins of the band
 };
 
 // MODE 0 psd, 1 magnitude, 2 band power: out[clip][frame] = sum of PSD bins [k_lo, k_hi] (A11, the spectrum is never written)
-template <typename R> constexpr int kOcc = sizeof(R) == 4 ? 4 : 2;      // waves per SIMD: 116-130 VGPRs in f32 (held to 128), 176-204 in f64
+template <typename R, int Q> constexpr int kOcc = (sizeof(R) == 4 && (Q & (Q - 1)) == 0) ? 4 : 2;      // waves per SIMD: 116-130 VGPRs in f32 (held to 128), 176-204 in f64; two where Q coefficients join them
 
 template <typename R, int Q, bool DETREND, int MODE>
-__global__ __launch_bounds__(64 * kWaves, kOcc<R>) void stft_rtiny_kernel(const TinyParams<R> p) {
+__global__ __launch_bounds__(64 * kWaves, (kOcc<R, Q>)) void stft_rtiny_kernel(const TinyParams<R> p) {
     constexpr int G = 64 / Q, N2 = 8 * Q, NB = N2 + 1;
-    constexpr int kStage = ((G * NB + 3) / 4) * 4 + 4;       // values per wave
+    constexpr bool kGen = (Q & (Q - 1)) != 0;                // Q no power of two: LDS / bpermute instead of DPP quad permutes
+    constexpr int kStage = kGen ? 16 * G * Q + 8 : ((G * NB + 3) / 4) * 4 + 4;       // values per wave (kGen: the cross-lane DFT's 8 G Q complex values, then the rows)
     constexpr int kVec = 16 / sizeof(R);                     // values per 16-byte store
     __shared__ __attribute__((aligned(16))) R lds[kWaves * kStage];
     const int lane = threadIdx.x & 63;
@@ -106,7 +112,8 @@ __global__ __launch_bounds__(64 * kWaves, kOcc<R>) void stft_rtiny_kernel(const 
     int64_t q = p.total_groups * lw / p.n_waves;
     const int64_t q_end = p.total_groups * (lw + 1) / p.n_waves;
 
-    const int j = lane % Q, g = lane / Q;
+    const bool live = lane < G * Q;                          // (kGen: the last lanes of the wave own no frame; they shadow frame G - 1 and store nothing)
+    const int j = lane % Q, g = live ? lane / Q : G - 1;
     const int k2 = Q == 4 ? ((j & 1) << 1) | (j >> 1) : j;   // the bin block this lane ends with
     // per-lane constants; sqrt of the PSD scale rides on the window (stft_r8x3.hip), bins 0 and N2 get 1/2 below
     const R sq = sqrt(MODE != 1 ? p.scale * static_cast<R>(0.5) : p.scale * static_cast<R>(0.25));
@@ -117,6 +124,10 @@ __global__ __launch_bounds__(64 * kWaves, kOcc<R>) void stft_rtiny_kernel(const 
         t1[r] = {p.tw[2 * (r * 64 + lane)], p.tw[2 * (r * 64 + lane) + 1]};
         st[r] = {p.tw[2 * ((8 + r) * 64 + lane)], p.tw[2 * ((8 + r) * 64 + lane) + 1]};
     }
+    cx<R> tq[kGen ? Q : 1];                                  // kGen: W_Q^(jj k2), jj < Q
+#pragma unroll
+    for (int jj = 0; jj < (kGen ? Q : 0); ++jj) tq[jj] = {p.tw[2 * ((16 + jj) * 64 + lane)], p.tw[2 * ((16 + jj) * 64 + lane) + 1]};
+    const int mirror = g * Q + (Q - 1 - j), mirror0 = g * Q + (Q - j) % Q;      // kGen: the lanes that hold bins N2 - k (k1 >= 1 / k1 = 0)
     // the quad DFT's per-lane coefficients: Q = 4 stage A u = partner + sA own; stage B out = A u + B partner(u);  Q = 2: out = partner + sA own
     const R sA = Q == 4 ? ((j & 2) ? -1 : 1) : (j ? -1 : 1);
     // lane 0: A = 1, B = 1;  lane 1: A = -1, B = 1;  lane 2: A = 1, B = -i;  lane 3: A = i, B = 1
@@ -124,6 +135,20 @@ __global__ __launch_bounds__(64 * kWaves, kOcc<R>) void stft_rtiny_kernel(const 
     const cx<R> cB = {static_cast<R>(j == 2 ? 0 : 1), static_cast<R>(j == 2 ? -1 : 0)};
     const R r0 = (MODE != 1 && k2 == 0) ? static_cast<R>(0.5) : static_cast<R>(1);      // bin 0 (register 0 of the k2 = 0 lane); bin N2 likewise
 
+    auto frame_sum = [&](R v) {                              // over the Q lanes of a frame, the same order in every lane
+        if (!kGen) {
+            v += quad<kXor1>(v);
+            if (Q == 4) v += quad<kXor2>(v);
+            return v;
+        }
+        if (live) stage[g * Q + j] = v;
+        wave_lds_fence();
+        R s = stage[g * Q];
+#pragma unroll
+        for (int jj = 1; jj < Q; ++jj) s += stage[g * Q + jj];
+        wave_lds_fence();
+        return s;
+    };
     auto load_group = [&](int clip, int gi, cx<R> (&dst)[8]) {
         const int f = min(gi * G + g, p.n_frames - 1);       // partial last group: recompute the last frame
         const R* const src = p.x + static_cast<int64_t>(clip) * p.clip_stride + static_cast<int64_t>(f) * p.hop + 2 * j;
@@ -151,9 +176,8 @@ __global__ __launch_bounds__(64 * kWaves, kOcc<R>) void stft_rtiny_kernel(const 
             R s = a[0].x + a[0].y;
 #pragma unroll
             for (int r = 1; r < 8; ++r) s += a[r].x + a[r].y;
-            s += quad<kXor1>(s);
-            if (Q == 4) s += quad<kXor2>(s);
-            const R mean = s * (static_cast<R>(1) / (2 * N2));
+            s = frame_sum(s);
+            const R mean = kGen ? s / static_cast<R>(2 * N2) : s * (static_cast<R>(1) / (2 * N2));     // (a true division where n is no power of two: a constant clip detrends to 0, as in scipy)
 #pragma unroll
             for (int r = 0; r < 8; ++r) { a[r].x -= mean; a[r].y -= mean; }
         }
@@ -162,8 +186,28 @@ __global__ __launch_bounds__(64 * kWaves, kOcc<R>) void stft_rtiny_kernel(const 
         radix8(a);                                           // over r -> k1
 #pragma unroll
         for (int k1 = 1; k1 < 8; ++k1) a[k1] = cmul(a[k1], t1[k1]);
+        if (kGen) {                                          // Q-point DFT across the frame's lanes, a direct sum through LDS
+            cx<R>* const cbuf = reinterpret_cast<cx<R>*>(stage);
+            if (live) {
 #pragma unroll
-        for (int k1 = 0; k1 < 8; ++k1) {                     // Q-point DFT across the quad's lanes -> this lane holds Z[k1 + 8 k2]
+                for (int k1 = 0; k1 < 8; ++k1) cbuf[(g * 8 + k1) * Q + j] = a[k1];
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (int k1 = 0; k1 < 8; ++k1) {
+                cx<R> acc = cbuf[(g * 8 + k1) * Q];          // jj = 0: coefficient 1
+#pragma unroll
+                for (int jj = 1; jj < (kGen ? Q : 1); ++jj) {
+                    const cx<R> b = cbuf[(g * 8 + k1) * Q + jj];
+                    acc.x = fma(b.x, tq[jj].x, fma(-b.y, tq[jj].y, acc.x));
+                    acc.y = fma(b.x, tq[jj].y, fma(b.y, tq[jj].x, acc.y));
+                }
+                a[k1] = acc;
+            }
+            wave_lds_fence();
+        }
+#pragma unroll
+        for (int k1 = 0; k1 < (kGen ? 0 : 8); ++k1) {        // Q-point DFT across the quad's lanes -> this lane holds Z[k1 + 8 k2]
             const cx<R> pa = Q == 4 ? quad<kXor2>(a[k1]) : quad<kXor1>(a[k1]);
             const cx<R> u = {fma(sA, a[k1].x, pa.x), fma(sA, a[k1].y, pa.y)};
             if (Q == 4) {
@@ -178,7 +222,8 @@ __global__ __launch_bounds__(64 * kWaves, kOcc<R>) void stft_rtiny_kernel(const 
 #pragma unroll
         for (int k1 = 0; k1 < 8; ++k1) {
             const cx<R> A = a[k1];
-            const cx<R> B = k1 == 0 ? (Q == 4 ? quad<kSwapHi>(a[0]) : a[0]) : (Q == 4 ? quad<kMirror>(a[8 - k1]) : quad<kXor1>(a[8 - k1]));
+            const cx<R> B = kGen ? cx<R>{__shfl(a[(8 - k1) % 8].x, k1 == 0 ? mirror0 : mirror), __shfl(a[(8 - k1) % 8].y, k1 == 0 ? mirror0 : mirror)}
+                          : k1 == 0 ? (Q == 4 ? quad<kSwapHi>(a[0]) : a[0]) : (Q == 4 ? quad<kMirror>(a[8 - k1]) : quad<kXor1>(a[8 - k1]));
             const cx<R> S = {A.x + B.x, A.y - B.y};
             const cx<R> D = {A.x - B.x, A.y + B.y};
             const cx<R> X = {S.x + fma(st[k1].x, D.y, st[k1].y * D.x), S.y + fma(st[k1].y, D.y, -st[k1].x * D.x)};
@@ -193,15 +238,16 @@ __global__ __launch_bounds__(64 * kWaves, kOcc<R>) void stft_rtiny_kernel(const 
         const int f = fg + g;
         if (MODE == 2) {
             if (k2 == 0 && N2 >= p.k_lo && N2 <= p.k_hi) bsum += pn;
-            bsum += quad<kXor1>(bsum);
-            if (Q == 4) bsum += quad<kXor2>(bsum);
-            if (j == 0 && f < p.n_frames) p.out[static_cast<int64_t>(clip) * p.out_clip_stride + f] = bsum;
+            bsum = frame_sum(bsum);
+            if (live && j == 0 && f < p.n_frames) p.out[static_cast<int64_t>(clip) * p.out_clip_stride + f] = bsum;
         } else {
             // the G rows of a group are G * NB consecutive values in HBM: through the slab, out as contiguous 16-byte stores (stft_rsmall.hip)
             R* const mine = stage + g * NB + 8 * k2;
+            if (live) {
 #pragma unroll
-            for (int k1 = 0; k1 < 8; ++k1) mine[k1] = pk[k1];
-            if (k2 == 0) stage[g * NB + N2] = pn;
+                for (int k1 = 0; k1 < 8; ++k1) mine[k1] = pk[k1];
+                if (k2 == 0) stage[g * NB + N2] = pn;
+            }
             wave_lds_fence();
             const int n_live = min(G, p.n_frames - fg) * NB;  // (wave-uniform; a partial last group writes fewer rows)
             R* const obase = p.out + static_cast<int64_t>(clip) * p.out_clip_stride + static_cast<int64_t>(fg) * NB;
@@ -243,7 +289,7 @@ int launch_q(const sg_plan& p, const StftArgs& a) {
     prm.hop = p.hop;
     prm.groups_per_clip = static_cast<int>((a.n_frames + G - 1) / G);
     prm.total_groups = static_cast<int64_t>(prm.groups_per_clip) * a.n_clips;
-    int64_t n_waves = static_cast<int64_t>(p.n_cu) * 4 * kOcc<R>;
+    int64_t n_waves = static_cast<int64_t>(p.n_cu) * 4 * kOcc<R, Q>;
     const int64_t by_work = prm.total_groups <= n_waves ? prm.total_groups : (prm.total_groups + 1) / 2;     // small calls: a group per wave
     if (n_waves > by_work) n_waves = by_work;
     if (n_waves < 1) n_waves = 1;
@@ -273,16 +319,26 @@ bool rtiny_can_run(const sg_plan& p, const StftArgs& a) {
 int launch_rtiny(const sg_plan& p, const StftArgs& a) {
     if (a.n_frames <= 0 || a.n_clips <= 0) return SG_OK;
     if (p.dtype == SG_F64) return p.nfft == 64 ? launch_q<double, 4>(p, a) : launch_q<double, 2>(p, a);
-    return p.nfft == 64 ? launch_q<float, 4>(p, a) : launch_q<float, 2>(p, a);
+    switch (p.nfft) {
+        case 32: return launch_q<float, 2>(p, a);
+        case 64: return launch_q<float, 4>(p, a);
+        case 96: return launch_q<float, 6>(p, a);
+        case 160: return launch_q<float, 10>(p, a);
+        case 192: return launch_q<float, 12>(p, a);
+        default: return launch_q<float, 14>(p, a);           // 224
+    }
 }
 
-// Per-lane twiddle table [16][64] complex (computed in long double), lane = Q g + j, k2 = the bin block of lane j:
+// Per-lane twiddle table [16 (+ Q)][64] complex (computed in long double), lane = Q g + j, k2 = the bin block of lane j:
 //   rows 0..7    exp(-2 pi i j k1 / N2)
 //   rows 8..15   exp(-2 pi i (k1 + 8 k2) / n)
+//   rows 16..    (Q no power of two) exp(-2 pi i jj k2 / Q), jj < Q
 int build_rtiny_tables(sg_plan& p) {
     const int n = p.nfft, N2 = n / 2, Q = N2 / 8;
+    const bool gen = (Q & (Q - 1)) != 0;
+    const int rows = 16 + (gen ? Q : 0);
     const long double two_pi = 6.283185307179586476925286766559005768L;
-    std::vector<long double> t(16 * 64 * 2);
+    std::vector<long double> t(static_cast<size_t>(rows) * 64 * 2);
     for (int lane = 0; lane < 64; ++lane) {
         const int j = lane % Q, k2 = Q == 4 ? ((j & 1) << 1) | (j >> 1) : j;
         for (int k1 = 0; k1 < 8; ++k1) {
@@ -290,6 +346,10 @@ int build_rtiny_tables(sg_plan& p) {
             const long double a2 = -two_pi * static_cast<long double>(k1 + 8 * k2) / n;
             t[2 * (k1 * 64 + lane)] = cosl(a1); t[2 * (k1 * 64 + lane) + 1] = sinl(a1);
             t[2 * ((8 + k1) * 64 + lane)] = cosl(a2); t[2 * ((8 + k1) * 64 + lane) + 1] = sinl(a2);
+        }
+        for (int jj = 0; gen && jj < Q; ++jj) {
+            const long double a3 = -two_pi * static_cast<long double>((jj * k2) % Q) / Q;
+            t[2 * ((16 + jj) * 64 + lane)] = cosl(a3); t[2 * ((16 + jj) * 64 + lane) + 1] = sinl(a3);
         }
     }
     if (p.dtype == SG_F64) {

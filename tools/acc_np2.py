@@ -7,7 +7,7 @@ from spectro import _capi
 from spectro.signal import plan_for
 from spectro.windows import get_window
 from oracle import stft_oracle as orc
-for n, hop, clips, frames in [(2080, 64, 3, 701), (4128, 96, 2, 1031), (2016, 64, 3, 701), (2048, 64, 3, 701), (8192, 64, 2, 641), (4096, 64, 2, 641)]:
+for n, hop, clips, frames in [(2080, 64, 3, 701), (4128, 96, 2, 1031), (2016, 64, 3, 701), (2048, 64, 3, 701), (8192, 64, 2, 641), (4096, 64, 2, 641), (96, 24, 5, 83), (224, 56, 5, 83), (128, 32, 5, 83)]:
     rng = np.random.default_rng(n * 7 + hop)
     ns = n + hop * (frames - 1) + 3
     x = (rng.standard_normal((clips, ns)) * 0.3 + 0.5).astype(np.float32)
@@ -15,7 +15,7 @@ for n, hop, clips, frames in [(2080, 64, 3, 701), (4128, 96, 2, 1031), (2016, 64
     plan = plan_for(get_window("hann", n), n, n, hop, 1, 48000.0, 0, 0, _capi.F32)
     _, _, so = orc.spectrogram(x.astype(np.float64), **kw)
     res = {}
-    names = [plan.kernel] + (["bluestein"] if plan.kernel.startswith("rblue") else ["stockham"])
+    names = [plan.kernel] + (["bluestein"] if (n & (n - 1)) else ["stockham"])
     for k in names:
         plan.force_kernel(k)
         _, _, s = sp.spectrogram(x, **kw)

@@ -13,7 +13,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 bad = 0
 fam = {}
 for it in range(cases):
-    nper = int(rng.choice([32, 64, 128, 128, 256, 256, 512, 512, 1024, 1024, 2048, 2048, 4096, 4096, 1000, 384, 6000, 96, 1504, 2016, 34, 960, 3008, 4100, 2082, 1500, 8192]))      # even non-powers of two: the register chirp-z kernels (round 4: one wave per frame up to 2048 / 1024 in f64, two to eight above; 2082, 4100: not a multiple of 4 / 8, LDS kernel)
+    nper = int(rng.choice([32, 64, 128, 128, 256, 256, 512, 512, 1024, 1024, 2048, 2048, 4096, 4096, 1000, 384, 6000, 96, 1504, 2016, 34, 960, 3008, 4100, 2082, 1500, 8192, 160, 192, 224]))      # even non-powers of two: the register chirp-z kernels (round 4: one wave per frame up to 2048 / 1024 in f64, two to eight above; 2082, 4100: not a multiple of 4 / 8, LDS kernel)
     r = rng.random()
     hop = int(rng.choice([64, 128, 256, 512])) if r < 0.5 else (nper - nper // 8 if r < 0.7 else int(rng.integers(1, nper + 1)))
     hop = max(1, min(hop, nper))

@@ -13,6 +13,40 @@ def quad(v, perm):
     return v[(lane & ~3) + np.asarray(perm)[lane & 3]]
 
 
+def run_general(Q):
+    """Q no power of two (nperseg 96 / 160 / 192 / 224): the cross-lane DFT as a direct sum, the split's partner in the mirror lane of the frame"""
+    G, N2 = 64 // Q, 8 * Q
+    n = 2 * N2
+    rng = np.random.default_rng(Q)
+    x = rng.standard_normal((G, n))
+    z = x[:, 0::2] + 1j * x[:, 1::2]
+    lane = np.arange(G * Q)
+    j, g = lane % Q, lane // Q
+    a = np.stack([z[g, j + Q * r] for r in range(8)], axis=1) @ w8
+    a = a * np.exp(-2j * np.pi * j[:, None] * np.arange(8)[None, :] / N2)
+    out = np.zeros_like(a)
+    for k1 in range(8):
+        for l in lane:
+            out[l, k1] = sum(a[g[l] * Q + jj, k1] * np.exp(-2j * np.pi * ((jj * j[l]) % Q) / Q) for jj in range(Q))
+    a, k2 = out, j
+    assert np.allclose(a, np.fft.fft(z, axis=1)[g[:, None], np.arange(8)[None, :] + 8 * k2[:, None]])
+    mirror, mirror0 = g * Q + (Q - 1 - j), g * Q + (Q - j) % Q
+    P = np.zeros((G, N2 + 1))
+    for k1 in range(8):
+        A = a[:, k1]
+        B = a[mirror0, 0] if k1 == 0 else a[mirror, 8 - k1]
+        k = k1 + 8 * k2
+        tw = np.exp(-2j * np.pi * k / n)
+        S = (A.real + B.real) + 1j * (A.imag - B.imag)
+        D = (A.real - B.real) + 1j * (A.imag + B.imag)
+        X = (S.real + tw.real * D.imag + tw.imag * D.real) + 1j * (S.imag + tw.imag * D.imag - tw.real * D.real)
+        P[g, k] = np.abs(X) ** 2 / 4
+    sel = k2 == 0
+    P[g[sel], N2] = (a[sel, 0].real - a[sel, 0].imag) ** 2
+    ref = np.abs(np.fft.rfft(x, axis=1)) ** 2
+    return np.abs(P - ref).max() / ref.max()
+
+
 def run(Q):
     G, N2 = 64 // Q, 8 * Q
     n = 2 * N2
@@ -58,3 +92,5 @@ def run(Q):
 if __name__ == "__main__":
     for Q in (4, 2):
         print("Q", Q, "nfft", 16 * Q, "max rel err", run(Q))
+    for Q in (6, 10, 12, 14):
+        print("Q", Q, "nfft", 16 * Q, "max rel err", run_general(Q))
