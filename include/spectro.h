@@ -127,7 +127,7 @@ int sg_plan_n_bins(const sg_plan* plan, int* n_bins);
 /* the scale factor the kernels multiply |X|^2 with (as double) */
 int sg_plan_scale(const sg_plan* plan, double* scale);
 /* name of the kernel family the plan dispatches to: "r8x3", "r8x3d" / "rsmalld" (f64 nperseg = nfft = 1024 / 128, 256, 512), "rsmall" (128, 256, 512),
- * "rbig", "rbigd", "rtiny" / "rtinyd" (32, 64), "rblue" / "rblued" (f32 / f64, even nperseg = nfft <= 2048 / 1024 that is no power of two: register
+ * "rbig", "rbigd", "rtiny" / "rtinyd" (32, 64, 96, 160, 192, 224), "rblue" / "rblued" (f32 / f64, even nperseg = nfft <= 2048 / 1024 that is no power of two: register
  * chirp-z), "rbluew" / "rbluewd" (the same up to 8192, nperseg a multiple of 4 / 8 / 16: two to eight wavefronts per frame; 8192 itself too),
  * "stockham", "bluestein" */
 const char* sg_plan_kernel(const sg_plan* plan);

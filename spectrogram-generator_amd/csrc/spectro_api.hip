@@ -38,7 +38,7 @@ static bool rsmall_ok(const sg_plan& p) {
 
 // nperseg 32 / 64, f32 and f64: the quad-DPP register kernel (stft_rtiny.hip)
 static bool rtiny_ok(const sg_plan& p) {
-    const bool small_np2 = p.dtype == SG_F32 && (p.nfft == 96 || p.nfft == 160 || p.nfft == 192 || p.nfft == 224);     // Q = 6 / 10 / 12 / 14 lanes per frame
+    const bool small_np2 = p.nfft == 96 || p.nfft == 160 || p.nfft == 192 || p.nfft == 224;     // Q = 6 / 10 / 12 / 14 lanes per frame
     return (p.dtype == SG_F32 || p.dtype == SG_F64) && p.nperseg == p.nfft && (p.nfft == 32 || p.nfft == 64 || small_np2) &&
            (p.detrend == SG_DETREND_NONE || p.detrend == SG_DETREND_CONSTANT) &&
            (p.mode == SG_MODE_PSD || p.mode == SG_MODE_MAGNITUDE);
@@ -237,7 +237,7 @@ static int run_stft(const sg_plan* plan, StftArgs& a) {
     if (a.in_i16 && (plan->kernel == Kernel::RSMALL || plan->kernel == Kernel::RBIG || (plan->kernel == Kernel::RTINY && plan->dtype == SG_F32)) && plan->hop % 2 == 0 &&
         (a.clip_stride % 2 == 0 || a.n_clips == 1) && static_cast<int64_t>(a.n_clips) * a.n_samples >= (1 << 18))
         return run_converted(plan, a);
-    if ((plan->kernel == Kernel::RBLUE || plan->kernel == Kernel::RBLUEW || (plan->kernel == Kernel::RTINY && !is_pow2(plan->nfft))) && a.in_i16)
+    if ((plan->kernel == Kernel::RBLUE || plan->kernel == Kernel::RBLUEW || (plan->kernel == Kernel::RTINY && !is_pow2(plan->nfft) && plan->dtype == SG_F32)) && a.in_i16)
         return run_converted(plan, a);                       // no chirp-z kernel loads int16 (nor does rtiny, whose fallback at these sizes is one)
     switch (plan->kernel) {
         case Kernel::R8X3: return launch_r8x3(*plan, a);
@@ -248,7 +248,9 @@ static int run_stft(const sg_plan* plan, StftArgs& a) {
         case Kernel::RTINY:
             if (rtiny_can_run(*plan, a)) return launch_rtiny(*plan, a);
             if (is_pow2(plan->nfft)) return launch_stockham(*plan, a);
-            return a.band_mode ? band_via_spectrum(plan, a) : launch_bluestein_lazy(plan, a);      // nperseg 96 / 160 / 192 / 224: odd hops, GUI-sized int16 calls
+            // nperseg 96 / 160 / 192 / 224 on an odd hop or an unaligned clip: the LDS chirp-z kernel
+            if (a.band_mode && plan->dtype == SG_F64) { set_error("band power of this plan needs an even hop and 16-byte aligned float64 input"); return SG_ERR_UNSUPPORTED; }
+            return a.band_mode ? band_via_spectrum(plan, a) : launch_bluestein_lazy(plan, a);
         case Kernel::STOCKHAM: return launch_stockham(*plan, a);
         case Kernel::BLUESTEIN: return launch_bluestein(*plan, a);
         // odd hops / unaligned clips, GUI-sized int16 calls: the LDS chirp-z kernel (its tables are built with the plan); it writes full spectra only

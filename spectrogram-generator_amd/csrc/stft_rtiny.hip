@@ -11,7 +11,7 @@
 // only stages the G finished rows (G * (N2 + 1) consecutive values in HBM) so that they leave as contiguous 16-byte stores, as in
 // stft_rsmall.hip.  Lane-level model of the index maps: tools/sim_rtiny.py.
 //
-// f32 only, nperseg 96 / 160 / 192 / 224 (Q = 6 / 10 / 12 / 14: the spin box's sizes below 256 that are no power of two; the chirp-z kernel ran
+// nperseg 96 / 160 / 192 / 224 (Q = 6 / 10 / 12 / 14: the spin box's sizes below 256 that are no power of two; the chirp-z kernel ran
 // them on 512-point transforms): the same frame layout on Q lanes (floor(64 / Q) frames per wave step, the last 4 or 8 lanes idle), the Q-point
 // DFT across the frame's lanes as a direct sum through LDS (Q complex multiply-adds per bin, the Q coefficients W_Q^(j k2) in registers), the
 // split's mirror lane by ds_bpermute.
@@ -318,7 +318,16 @@ bool rtiny_can_run(const sg_plan& p, const StftArgs& a) {
 
 int launch_rtiny(const sg_plan& p, const StftArgs& a) {
     if (a.n_frames <= 0 || a.n_clips <= 0) return SG_OK;
-    if (p.dtype == SG_F64) return p.nfft == 64 ? launch_q<double, 4>(p, a) : launch_q<double, 2>(p, a);
+    if (p.dtype == SG_F64) {
+        switch (p.nfft) {
+            case 32: return launch_q<double, 2>(p, a);
+            case 64: return launch_q<double, 4>(p, a);
+            case 96: return launch_q<double, 6>(p, a);
+            case 160: return launch_q<double, 10>(p, a);
+            case 192: return launch_q<double, 12>(p, a);
+            default: return launch_q<double, 14>(p, a);      // 224
+        }
+    }
     switch (p.nfft) {
         case 32: return launch_q<float, 2>(p, a);
         case 64: return launch_q<float, 4>(p, a);

@@ -669,10 +669,10 @@ _RTINY_NP2 = [(96, 24, "constant", "psd"), (96, None, "constant", "psd"), (96, 2
               (192, 48, "constant", "magnitude"), (192, None, "constant", "psd"), (224, 56, "constant", "psd"), (224, None, "constant", "psd"), (224, 2, False, "psd")]
 
 
-@pytest.mark.parametrize("dt,n,hop,detrend,mode", [(dt, *c) for dt in ("float32", "float64") for c in _RTINY_POW2] + [("float32", *c) for c in _RTINY_NP2])
+@pytest.mark.parametrize("dt,n,hop,detrend,mode", [(dt, *c) for dt in ("float32", "float64") for c in _RTINY_POW2 + _RTINY_NP2])
 def test_rtiny_kernel(sp, dt, n, hop, detrend, mode):
     """The smallest sizes of the spin box (GUI.py:87-89: 32, 64): the quad-DPP register kernel (stft_rtiny.hip, round 4: 16 / 32 frames per
-    wave, no LDS in the transform) in f32 and f64 -- and, f32, its form for nperseg 96 / 160 / 192 / 224 (6 ... 14 lanes per frame, the cross-lane
+    wave, no LDS in the transform) in f32 and f64 -- and its form for nperseg 96 / 160 / 192 / 224 (6 ... 14 lanes per frame, the cross-lane
     DFT as a direct sum through LDS) -- vs the oracle and vs the Stockham / LDS chirp-z kernel of the same plan, frame counts that are no
     multiple of the group size, several clips incl. all-zero and constant ones, the fused band power, int16 and the odd-hop fallback."""
     from spectro import _capi
@@ -1248,7 +1248,7 @@ def test_rbluew_f64_many_frames(sp, n, hop, clips, frames):
 
 @pytest.mark.parametrize("n,hop,detrend,mode,window", [
     (1000, 250, "constant", "psd", "hann"), (1000, 875, "constant", "psd", ("tukey", 0.25)), (960, 240, False, "magnitude", "hann"),
-    (96, 24, "constant", "psd", ("tukey", 0.25)), (480, 419, "constant", "psd", "hann"), (6, 2, "constant", "psd", "boxcar"),
+    (288, 72, "constant", "psd", ("tukey", 0.25)), (480, 419, "constant", "psd", "hann"), (6, 2, "constant", "psd", "boxcar"),
     (34, 30, False, "psd", "hann"), (1022, 2, "constant", "magnitude", "hann"), (514, 128, "constant", "psd", "boxcar")])
 def test_rblue_f64_kernel(sp, n, hop, detrend, mode, window):
     """The reference's own flow at a non-power-of-two nperseg: float64 recordings (SweepManager.py:135-136) and the spin box's 32-steps
