@@ -1148,9 +1148,9 @@ def test_rbluew_many_frames_band_power_and_int16(sp, n, hop, clips, frames):
     _, _, so = orc.spectrogram(x, **kw)
     assert s.shape == so.shape == (clips, n // 2 + 1, frames)
     # (per-bin bound 3e-4 over these 1-2 M bins: the tail of float32 rounding at bins 1e-3 of the frame maximum -- scipy's own float32
-    # path shows 1.8e-4 / 2.0e-4 on the same inputs, this kernel 1.3e-4 / 1.7e-4, tools/acc_np2.py; frame and norm bounds as everywhere)
+    # path shows 1.2e-4 / 2.0e-4 on the same inputs, this kernel 1.3e-4 / 2.0e-4, tools/acc_np2.py; frame and norm bounds as everywhere)
     # (nperseg 8192, 5.2 M bins: 6e-4 -- the oracle computes in the input's precision as scipy does, so BOTH sides carry float32 rounding: against
-    # float64 truth this kernel shows 2.0e-4, scipy's float32 path 2.7e-4, tools/acc_np2.py)
+    # float64 truth this kernel shows 1.9e-4, scipy's float32 path 2.0e-4, tools/acc_np2.py)
     assert_spec_close(s, so, time_axis=-1, bin_rtol=3e-4 if n < 8192 else 6e-4)
     nfr, nb = plan.n_frames(ns), n // 2 + 1
     d_in, d_bp = _capi.DeviceBuffer(x.nbytes), _capi.DeviceBuffer(clips * nfr * 4)
